@@ -1,0 +1,102 @@
+/* qttt.h — C ABI of libqttt_hip.so, the MI355X (gfx950) vectorised Quantum Tic-Tac-Toe
+ * environment.  This is the drop-in boundary for the reference's Env.step() hot path
+ * (Oxel40/qtttgym @ v1): each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (contiguous; torch-ROCm tensors in the host package), nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and ordered by it;
+ *     no call synchronises the device;
+ *   - return value: 0 = ok, >0 = hipError_t of the launch, <0 = argument error
+ *     (QTTT_ERR_NULL / QTTT_ERR_SIZE / QTTT_ERR_ACTION);
+ *   - the library is stateless, hence re-entrant;
+ *   - illegal *actions* are data, not errors: they are noops exactly as env.py:36-43.
+ *
+ * State: an opaque device buffer of qttt_state_bytes(n) bytes for n boards (20 B/board,
+ * structure-of-arrays: u64 plane A[n], u64 plane B[n], u32 plane C[n]).
+ */
+#ifndef QTTT_H
+#define QTTT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QTTT_ABI_VERSION 1
+
+#define QTTT_ERR_NULL   (-1)
+#define QTTT_ERR_SIZE   (-2)
+#define QTTT_ERR_ACTION (-3)
+
+/* qttt_step / qttt_sample_actions flags */
+#define QTTT_FLAG_AUTO_RESET 1u   /* a board whose previous step returned terminated is
+                                     re-initialised before the action is applied (the build's
+                                     throughput mode; the reference has no auto-reset) */
+
+int     qttt_abi_version(void);
+/* bytes of device memory needed for n boards */
+int64_t qttt_state_bytes(int64_t n);
+
+/* Env.reset / Env.__init__ (env.py:55-57, 16-32) -> Board.__init__ (board.py:2-7), n boards */
+int qttt_reset(void *state, int64_t n, void *stream);
+
+/* Env.step (env.py:34-53) for n boards = Board.make_move (board.py:9-25) +
+ * Board.update_qstructs (board.py:27-69) + QEvalClassic.eval (qeval.py:5-51) +
+ * Board.check_win (board.py:71-115) + reward/terminated (env.py:49,51), one fused kernel.
+ *   actions    u8[n,2]   action[0], action[1] per board (env.py:37-38); anything that makes
+ *                        make_move raise (a==b, classical square, >8) is a noop
+ *   bits       u8[n] or NULL. Stand-in for random.choice at qeval.py:35: 0 -> the closing move
+ *                        collapses onto min(a,b), 1 -> onto max(a,b); read only on a collapse.
+ *                        NULL -> bit = counter hash of (seed, board_offset+i, step_idx)
+ *   reward     f32[n]    -0.0f or -1.0f (env.py:49; sign bit is part of the contract)
+ *   terminated u8[n]     env.py:51
+ */
+int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+              uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+              uint8_t *terminated, int64_t n, void *stream);
+
+/* n_steps consecutive qttt_step launches enqueued back to back from C, so a replay / rollout
+ * loop is not paced by the host interpreter.  Step t (0-based) reads actions + t*2n and
+ * bits + t*n (when bits != NULL), uses step_idx0 + t, and writes reward + t*out_stride and
+ * terminated + t*out_stride (out_stride 0: every step overwrites the same n outputs). */
+int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                   uint32_t step_idx0, int64_t board_offset, uint32_t flags, float *reward,
+                   uint8_t *terminated, int64_t out_stride, int64_t n, int32_t n_steps,
+                   void *stream);
+
+/* Env._observation (env.py:68-85) for n boards.
+ *   classical i8[n,9]   Board.board (-1 empty else round)
+ *   q_p1 u8[n,5,2], q_p1_len u8[n]   un-collapsed even-round moves (lo,hi) in move order, 255 pad
+ *   q_p2 u8[n,4,2], q_p2_len u8[n]   un-collapsed odd-round moves
+ *   turn u8[n]          len(moves) % 2
+ */
+int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
+                 uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream);
+
+/* Board.check_win (board.py:71-115): p1_round i8[n], p2_round i8[n] (-1 = no line) */
+int qttt_check_win(const void *state, int8_t *p1_round, int8_t *p2_round, int64_t n,
+                   void *stream);
+
+/* The Board attributes L3 callers read and assign (board.py:4-6; mcts.py:11-17,241):
+ *   moves u8[n,9,2] (255 pad), n_moves u8[n], board i8[n,9], qmask u16[n,4] (qstructs in list
+ *   order as 9-bit square masks, 0 pad), n_q u8[n] */
+int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *board,
+                uint16_t *qmask, uint8_t *n_q, int64_t n, void *stream);
+int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
+                const uint16_t *qmask, const uint8_t *n_q, int64_t n, void *stream);
+
+/* Synthetic policy for measurement: uniform over legal unordered pairs
+ * (GameState.actions rule, mcts.py:20-27) in ind2move order (mcts.py:339-343), index and
+ * collapse bit from the counter hash of (seed, board_offset+i, step_idx).  actions u8[n,2]. */
+int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx,
+                        int64_t board_offset, uint32_t flags, uint8_t *actions, int64_t n,
+                        void *stream);
+
+/* The counter hash itself (host-callable, no device work), so callers can reproduce bits. */
+uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""ctypes binding of libqttt_hip.so (include/qttt.h).  There is no CPU fallback: if the HIP
+library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqttt_hip.so")
+
+ABI_VERSION = 1
+FLAG_AUTO_RESET = 1
+
+# every symbol include/qttt.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u64, _u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
+                               ctypes.c_uint32)
+SIGNATURES = {
+    "qttt_abi_version": (_i32, []),
+    "qttt_state_bytes": (_i64, [_i64]),
+    "qttt_reset": (_i32, [_vp, _i64, _vp]),
+    "qttt_step": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
+    "qttt_step_many": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "qttt_observe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_check_win": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "qttt_export": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_import": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
+    "qttt_hash": (_u64, [_u64, _u64, _u32]),
+}
+
+_lib = None
+
+
+class QtttNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the HIP library (once).  Raises QtttNativeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QtttNativeError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.qttt_abi_version() != ABI_VERSION:
+            raise QtttNativeError("libqttt_hip.so ABI %d != expected %d (stale build?)"
+                                  % (L.qttt_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+_ARG_ERRORS = {-1: "null pointer", -2: "bad size / offset", -3: "misaligned actions"}
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc < 0:
+            raise QtttNativeError("%s: argument error %d (%s)" % (what, rc, _ARG_ERRORS.get(rc, "?")))
+        raise QtttNativeError("%s: hipError_t %d" % (what, rc))

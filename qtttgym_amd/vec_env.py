@@ -1,0 +1,233 @@
+"""VecEnv — N independent Quantum Tic-Tac-Toe boards advanced per call on one MI355X.
+
+Same method names as the reference's gymnasium-style `Env` (env.py:15-85): reset / step /
+observ / turn / action_space / observation_space, returning tensors of leading dimension N.
+All arithmetic happens in libqttt_hip.so (include/qttt.h); torch is used for device memory
+and streams only.
+"""
+import torch
+
+from . import _native
+from .spaces import reference_action_space, reference_observation_space
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class VecEnv:
+    def __init__(self, num_envs, device="cuda", seed=0, auto_reset=False, board_offset=0):
+        self.num_envs = int(num_envs)
+        if self.num_envs < 0:
+            raise ValueError("num_envs must be >= 0")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.QtttNativeError(
+                "VecEnv runs on an MI355X through libqttt_hip.so only (device=%r); there is no "
+                "CPU path" % (device,))
+        if not torch.cuda.is_available():
+            raise _native.QtttNativeError("no HIP device visible (torch.cuda.is_available() is False)")
+        self._lib = _native.lib()
+        self.seed = int(seed)
+        self.auto_reset = bool(auto_reset)
+        self.board_offset = int(board_offset)     # global index of board 0 (multi-GPU shards)
+        self.step_idx = 0
+        self.action_space = reference_action_space()
+        self.observation_space = reference_observation_space()
+        n = self.num_envs
+        with torch.cuda.device(self.device):
+            self.state = torch.empty(int(self._lib.qttt_state_bytes(n)), dtype=torch.uint8, device=self.device)
+            self._reward = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._terminated = torch.empty(n, dtype=torch.bool, device=self.device)
+            self._truncated = torch.zeros(n, dtype=torch.bool, device=self.device)  # env.py:52
+        self.reset()
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _flags(self):
+        return _native.FLAG_AUTO_RESET if self.auto_reset else 0
+
+    def _as_actions(self, actions):
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(actions)
+        if actions.shape != (self.num_envs, 2):
+            raise ValueError("actions must have shape (%d, 2), got %s" % (self.num_envs, tuple(actions.shape)))
+        if actions.dtype != torch.uint8:
+            # anything outside 0..8 is a noop in the reference (IndexError swallowed at env.py:41);
+            # map it to 255 before narrowing so that e.g. 256 does not wrap to square 0
+            a = actions.to(torch.int64)
+            actions = torch.where((a < 0) | (a > 255), torch.full_like(a, 255), a).to(torch.uint8)
+        return actions.to(self.device).contiguous()
+
+    # ------------------------------------------------------------------ gym surface
+    def reset(self, *, seed=None, options=None):
+        """env.py:55-57: fresh boards; `seed`/`options` accepted and ignored like the reference,
+        except that an int `seed` re-keys the collapse-bit hash (the reference has no per-env RNG)."""
+        if seed is not None:
+            self.seed = int(seed)
+        self.step_idx = 0
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.qttt_reset(self.state.data_ptr(), self.num_envs, self._stream()),
+                          "qttt_reset")
+        return self.observ(), {}
+
+    def step_raw(self, actions, bits=None):
+        """The hot path alone: one fused kernel launch, no observation unpack.
+        actions u8[N,2] on the device; bits u8[N] (explicit collapse bits, parity mode) or None
+        (bit = counter hash of (seed, board_offset+i, step_idx)).
+        Returns (reward f32[N], terminated bool[N]) — buffers reused across calls."""
+        n = self.num_envs
+        if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.state.device \
+                or actions.numel() != 2 * n:
+            raise ValueError("step_raw wants a contiguous uint8 device tensor of shape (N, 2)")
+        if bits is not None and (bits.dtype != torch.uint8 or not bits.is_contiguous()
+                                 or bits.device != self.state.device or bits.numel() != n):
+            raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
+        with torch.cuda.device(self.device):
+            rc = self._lib.qttt_step(self.state.data_ptr(), actions.data_ptr(), _ptr(bits), self.seed,
+                                     self.step_idx, self.board_offset, self._flags(),
+                                     self._reward.data_ptr(), self._terminated.data_ptr(), n,
+                                     self._stream())
+        _native.check(rc, "qttt_step")
+        self.step_idx += 1
+        return self._reward, self._terminated
+
+    def step_many(self, actions, bits=None, reward=None, terminated=None):
+        """T consecutive steps from pre-recorded device tensors actions u8[T,N,2] (bits u8[T,N]),
+        enqueued from C with no per-step host work.  With `reward`/`terminated` of shape [T,N]
+        every step's outputs are kept; otherwise only the last step's (returned)."""
+        n = self.num_envs
+        T = int(actions.shape[0])
+        if actions.dtype != torch.uint8 or not actions.is_contiguous() or tuple(actions.shape) != (T, n, 2) \
+                or actions.device != self.state.device:
+            raise ValueError("step_many wants a contiguous uint8 device tensor of shape (T, N, 2)")
+        if bits is not None and (bits.dtype != torch.uint8 or not bits.is_contiguous()
+                                 or tuple(bits.shape) != (T, n) or bits.device != self.state.device):
+            raise ValueError("bits must be a contiguous uint8 device tensor of shape (T, N)")
+        stride = 0
+        r, tm = self._reward, self._terminated
+        if reward is not None or terminated is not None:
+            if reward is None or terminated is None or tuple(reward.shape) != (T, n) \
+                    or tuple(terminated.shape) != (T, n) or reward.dtype != torch.float32 \
+                    or terminated.dtype != torch.bool or not reward.is_contiguous() \
+                    or not terminated.is_contiguous():
+                raise ValueError("reward f32[T,N] and terminated bool[T,N] must be given together")
+            r, tm, stride = reward, terminated, n
+        with torch.cuda.device(self.device):
+            rc = self._lib.qttt_step_many(self.state.data_ptr(), actions.data_ptr(), _ptr(bits), self.seed,
+                                          self.step_idx, self.board_offset, self._flags(), r.data_ptr(),
+                                          tm.data_ptr(), stride, n, T, self._stream())
+        _native.check(rc, "qttt_step_many")
+        self.step_idx += T
+        return r, tm
+
+    def step(self, actions, bits=None, verbose=False):
+        """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info)."""
+        actions = self._as_actions(actions)
+        if bits is not None:
+            bits = torch.as_tensor(bits).to(torch.uint8).to(self.device).contiguous()
+        reward, terminated = self.step_raw(actions, bits)
+        return self.observ(), reward, terminated, self._truncated, {}
+
+    def observ(self):
+        """env.py:62-63,68-85 as tensors: q_states_p{1,2} u8[N,5|4,2] (255 pad) with *_len,
+        classical i8[N,9], turn u8[N]."""
+        n = self.num_envs
+        dev = self.device
+        with torch.cuda.device(dev):
+            obs = {
+                "q_states_p1": torch.empty((n, 5, 2), dtype=torch.uint8, device=dev),
+                "q_states_p1_len": torch.empty(n, dtype=torch.uint8, device=dev),
+                "q_states_p2": torch.empty((n, 4, 2), dtype=torch.uint8, device=dev),
+                "q_states_p2_len": torch.empty(n, dtype=torch.uint8, device=dev),
+                "classical": torch.empty((n, 9), dtype=torch.int8, device=dev),
+                "turn": torch.empty(n, dtype=torch.uint8, device=dev),
+            }
+            rc = self._lib.qttt_observe(self.state.data_ptr(), obs["classical"].data_ptr(),
+                                        obs["q_states_p1"].data_ptr(), obs["q_states_p1_len"].data_ptr(),
+                                        obs["q_states_p2"].data_ptr(), obs["q_states_p2_len"].data_ptr(),
+                                        obs["turn"].data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_observe")
+        return obs
+
+    def turn(self):
+        """env.py:65-66: len(moves) per board (counts the autofill move)."""
+        return self.export_boards()["n_moves"]
+
+    def render(self, index=0):
+        from .board import Board, displayBoard
+        displayBoard(Board.from_export(self.export_boards(), index))
+
+    # ------------------------------------------------------------------ Board-level access
+    def check_win(self):
+        """board.py:71-115 per board: (p1_round i8[N], p2_round i8[N])."""
+        n = self.num_envs
+        with torch.cuda.device(self.device):
+            p1 = torch.empty(n, dtype=torch.int8, device=self.device)
+            p2 = torch.empty(n, dtype=torch.int8, device=self.device)
+            rc = self._lib.qttt_check_win(self.state.data_ptr(), p1.data_ptr(), p2.data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_check_win")
+        return p1, p2
+
+    def export_boards(self):
+        """Board.moves / .board / .qstructs (board.py:4-6) as tensors."""
+        n = self.num_envs
+        dev = self.device
+        with torch.cuda.device(dev):
+            out = {
+                "moves": torch.empty((n, 9, 2), dtype=torch.uint8, device=dev),
+                "n_moves": torch.empty(n, dtype=torch.uint8, device=dev),
+                "board": torch.empty((n, 9), dtype=torch.int8, device=dev),
+                "qmask": torch.empty((n, 4), dtype=torch.int16, device=dev),
+                "n_q": torch.empty(n, dtype=torch.uint8, device=dev),
+            }
+            rc = self._lib.qttt_export(self.state.data_ptr(), out["moves"].data_ptr(),
+                                       out["n_moves"].data_ptr(), out["board"].data_ptr(),
+                                       out["qmask"].data_ptr(), out["n_q"].data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_export")
+        return out
+
+    def import_boards(self, moves, n_moves, board, qmask, n_q):
+        n = self.num_envs
+        dev = self.device
+
+        def prep(t, dtype, shape):
+            t = torch.as_tensor(t).to(dtype).to(dev).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError("expected shape %s, got %s" % (shape, tuple(t.shape)))
+            return t
+        moves = prep(moves, torch.uint8, (n, 9, 2))
+        n_moves = prep(n_moves, torch.uint8, (n,))
+        board = prep(board, torch.int8, (n, 9))
+        qmask = prep(qmask, torch.int16, (n, 4))
+        n_q = prep(n_q, torch.uint8, (n,))
+        with torch.cuda.device(dev):
+            rc = self._lib.qttt_import(self.state.data_ptr(), moves.data_ptr(), n_moves.data_ptr(),
+                                       board.data_ptr(), qmask.data_ptr(), n_q.data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_import")
+
+    def sample_actions(self, out=None):
+        """Uniform-legal synthetic policy for the *next* step."""
+        n = self.num_envs
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((n, 2), dtype=torch.uint8, device=self.device)
+            rc = self._lib.qttt_sample_actions(self.state.data_ptr(), self.seed, self.step_idx,
+                                               self.board_offset, self._flags(), out.data_ptr(), n,
+                                               self._stream())
+        _native.check(rc, "qttt_sample_actions")
+        return out
+
+    # ------------------------------------------------------------------ checkpointing
+    def state_dict(self):
+        return {"state": self.state.clone(), "seed": self.seed, "step_idx": self.step_idx,
+                "board_offset": self.board_offset, "auto_reset": self.auto_reset}
+
+    def load_state_dict(self, sd):
+        if sd["state"].numel() != self.state.numel():
+            raise ValueError("state size mismatch")
+        self.state.copy_(sd["state"])
+        self.seed, self.step_idx = int(sd["seed"]), int(sd["step_idx"])
+        self.board_offset, self.auto_reset = int(sd["board_offset"]), bool(sd["auto_reset"])

@@ -1,0 +1,89 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/qttt.h declares,
+the binding table matches the header, the product never imports the oracle, host-side helpers."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "qttt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qttt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build_hip()
+    from qtttgym_amd import _native
+    L = ctypes.CDLL(_native.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(_native.SIGNATURES) == syms
+    assert L.qttt_abi_version() == _native.ABI_VERSION
+
+
+def test_state_bytes_and_hash_are_host_callable():
+    from qtttgym_amd import _native
+    import oracle
+    L = _native.lib()
+    assert L.qttt_state_bytes(0) == 0
+    assert L.qttt_state_bytes(1 << 20) == 20 * (1 << 20)
+    assert L.qttt_state_bytes(-1) < 0
+    for seed, bid, step in [(0, 0, 0), (1, 123456789, 7), (2**63 + 5, 2**33 + 17, 2**31 + 3)]:
+        assert L.qttt_hash(seed, bid, step) == oracle.hash64(seed, bid, step)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "qtttgym_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "qttt_oracle" not in src and "libqttt_oracle" not in src, f
+
+
+def test_no_cpu_fallback():
+    import torch
+    from qtttgym_amd import VecEnv, _native
+    with pytest.raises(_native.QtttNativeError):
+        VecEnv(8, device="cpu")
+    if not torch.cuda.is_available():
+        with pytest.raises(_native.QtttNativeError):
+            VecEnv(8)
+
+
+def test_spaces_match_reference_declarations():
+    from qtttgym_amd.spaces import reference_action_space, reference_observation_space
+    a = reference_action_space()
+    assert len(a) == 2 and a[0].n == 9 and a[1].n == 9          # env.py:19
+    o = reference_observation_space()
+    assert set(o.keys()) == {"q_states_p1", "q_states_p2", "classical", "turn"}
+    assert o["q_states_p1"].max_len == 5 and o["q_states_p2"].max_len == 4   # env.py:20-21
+    assert o["classical"].shape == (9,) and o["turn"].n == 2
+    assert a.contains((3, 8)) and not a.contains((3, 9))
+
+
+def test_display_board_matches_reference_layout(capsys):
+    from qtttgym_amd.board import Board, QEvalClassic, displayBoard
+    b = Board(QEvalClassic())
+    b.moves = [(0, 1, 0), (0, 1, 1), (4, 8, 2)]
+    b.board = [1, 0, -1, -1, -1, -1, -1, -1, -1]
+    displayBoard(b)
+    out = capsys.readouterr().out
+    lines = out.splitlines()
+    assert lines[0] == "+---+---+---+" and len(lines) == 14
+    assert lines[1] == "| o |x x|   |" and lines[2] == "|o1o| 0 |   |" and lines[3] == "| o |x x|   |"
+    assert lines[5] == "|   |  2|   |"
+
+
+def test_oracle_ind2move_table():
+    import oracle
+    pairs = [oracle.ind2move(a) for a in range(36)]
+    assert pairs == [(i, j) for i in range(9) for j in range(i + 1, 9)]

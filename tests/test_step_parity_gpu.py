@@ -1,0 +1,196 @@
+"""T2: the HIP path (through the C ABI, via qtttgym_amd.VecEnv) against
+  (a) the golden traces recorded from the unmodified reference, and
+  (b) the C oracle on seeded inputs at BASELINE.json's batch sizes.
+Bit-exact: integer state, reward compared as IEEE bits (-0.0 matters, env.py:49)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def assert_same_as_oracle(env, ob, tag=""):
+    ex = {k: _np(v) for k, v in env.export_boards().items()}
+    assert np.array_equal(ex["board"], ob.board), tag
+    assert np.array_equal(ex["n_moves"], ob.n_moves), tag
+    assert np.array_equal(ex["moves"], ob.moves), tag
+    assert np.array_equal(ex["n_q"], ob.n_q), tag
+    assert np.array_equal(ex["qmask"].view(np.uint16), ob.qmask), tag
+
+
+def test_golden_traces_through_hip(golden):
+    from qtttgym_amd import VecEnv
+    acts, bits = golden["actions"], golden["bits"]
+    E, T = bits.shape
+    env = VecEnv(E)
+    for t in range(T):
+        obs, reward, term, trunc, info = env.step(torch.from_numpy(acts[:, t].copy()),
+                                                  torch.from_numpy(bits[:, t].copy()))
+        assert info == {} and not bool(trunc.any())
+        ex = {k: _np(v) for k, v in env.export_boards().items()}
+        assert np.array_equal(ex["board"], golden["board"][:, t]), t
+        assert np.array_equal(ex["moves"], golden["moves"][:, t]), t
+        assert np.array_equal(ex["n_moves"], golden["n_moves"][:, t]), t
+        assert np.array_equal(ex["qmask"].view(np.uint16), golden["qmask"][:, t]), t
+        assert np.array_equal(ex["n_q"], golden["n_q"][:, t]), t
+        want = golden["reward"][:, t].astype(np.float32).view(np.uint32)
+        assert np.array_equal(_np(reward).view(np.uint32), want), t
+        assert np.array_equal(_np(term).astype(np.uint8), golden["terminated"][:, t]), t
+        assert np.array_equal(_np(obs["classical"]), golden["board"][:, t]), t
+        assert np.array_equal(_np(obs["q_states_p1"]), golden["q_p1"][:, t]), t
+        assert np.array_equal(_np(obs["q_states_p1_len"]), golden["q_p1_len"][:, t]), t
+        assert np.array_equal(_np(obs["q_states_p2"]), golden["q_p2"][:, t]), t
+        assert np.array_equal(_np(obs["q_states_p2_len"]), golden["q_p2_len"][:, t]), t
+        assert np.array_equal(_np(obs["turn"]), golden["turn"][:, t]), t
+        p1, p2 = env.check_win()
+        assert np.array_equal(_np(p1), golden["p1_round"][:, t]), t
+        assert np.array_equal(_np(p2), golden["p2_round"][:, t]), t
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 4096, 262144])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_hip_vs_oracle_uniform_policy_hash_bits(n, auto_reset):
+    """Policy kernel + step kernel with in-kernel hash bits vs the oracle, 14 steps
+    (episodes last <= 9 steps, so with auto_reset every board restarts at least once)."""
+    from qtttgym_amd import VecEnv
+    seed, off = 1234 + n, 7 * n
+    env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    for t in range(14):
+        a_hip = env.sample_actions()
+        a_or = ob.sample_actions(seed, t, off, auto_reset)
+        assert np.array_equal(_np(a_hip), a_or), t
+        reward, term = env.step_raw(a_hip)
+        r_or, t_or = ob.step(a_or, None, seed, t, off, auto_reset)
+        assert np.array_equal(_np(reward).view(np.uint32), r_or.view(np.uint32)), t
+        assert np.array_equal(_np(term).astype(np.uint8), t_or), t
+        assert_same_as_oracle(env, ob, t)
+
+
+def test_hip_vs_oracle_random_garbage_actions():
+    """Arbitrary bytes as actions (mostly noops) + explicit bits."""
+    from qtttgym_amd import VecEnv
+    n = 8192
+    rng = np.random.default_rng(5)
+    env = VecEnv(n)
+    ob = oracle.OracleBoards(n)
+    for t in range(40):
+        hi = 256 if t % 3 == 0 else 10
+        acts = rng.integers(0, hi, size=(n, 2), dtype=np.uint8)
+        bits = rng.integers(0, 256, size=n, dtype=np.uint8)   # only bit 0 counts
+        reward, term = env.step_raw(torch.from_numpy(acts).cuda(), torch.from_numpy(bits).cuda())
+        r_or, t_or = ob.step(acts, bits)
+        assert np.array_equal(_np(reward).view(np.uint32), r_or.view(np.uint32)), t
+        assert np.array_equal(_np(term).astype(np.uint8), t_or), t
+        assert_same_as_oracle(env, ob, t)
+
+
+def test_full_size_one_million_boards_vs_oracle():
+    """BASELINE metric size: 1 048 576 boards, auto-reset throughput mode, 12 steps."""
+    from qtttgym_amd import VecEnv
+    n = 1 << 20
+    env = VecEnv(n, seed=3, auto_reset=True)
+    ob = oracle.OracleBoards(n)
+    n_term = 0
+    for t in range(12):
+        a = env.sample_actions()
+        reward, term = env.step_raw(a)
+        a_np = _np(a)
+        r_or, t_or = ob.step(a_np, None, 3, t, 0, True)
+        assert np.array_equal(_np(term).astype(np.uint8), t_or), t
+        assert np.array_equal(_np(reward).view(np.uint32), r_or.view(np.uint32)), t
+        n_term += int(t_or.sum())
+    assert_same_as_oracle(env, ob)
+    assert n_term > n  # every board finished at least one episode on average
+
+
+def test_export_import_round_trip_continues_identically():
+    from qtttgym_amd import VecEnv
+    n = 4096
+    env = VecEnv(n, seed=11)
+    for t in range(5):
+        env.step_raw(env.sample_actions())
+    ex = env.export_boards()
+    env2 = VecEnv(n, seed=11)
+    env2.import_boards(ex["moves"], ex["n_moves"], ex["board"], ex["qmask"], ex["n_q"])
+    env2.step_idx = env.step_idx
+    ex2 = env2.export_boards()
+    for k in ex:
+        assert torch.equal(ex[k], ex2[k]), k
+    for t in range(6):
+        a = env.sample_actions()
+        a2 = env2.sample_actions()
+        assert torch.equal(a, a2)
+        r1, t1 = env.step_raw(a)
+        r1, t1 = r1.clone(), t1.clone()
+        r2, t2 = env2.step_raw(a2)
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(t1, t2)
+        e1, e2 = env.export_boards(), env2.export_boards()
+        for k in e1:
+            assert torch.equal(e1[k], e2[k]), (t, k)
+
+
+def test_shard_equals_slice_of_single_run():
+    """T4: shard k of a G-way run == boards [kN/G,(k+1)N/G) of the 1-GPU run (global board ids
+    key the hash)."""
+    from qtttgym_amd import VecEnv
+    n, G = 8192, 4
+    full = VecEnv(n, seed=21, auto_reset=True)
+    shards = [VecEnv(n // G, seed=21, auto_reset=True, board_offset=k * (n // G)) for k in range(G)]
+    for t in range(12):
+        a = full.sample_actions()
+        r, tm = full.step_raw(a)
+        for k, sh in enumerate(shards):
+            sl = slice(k * (n // G), (k + 1) * (n // G))
+            ak = sh.sample_actions()
+            assert torch.equal(ak, a[sl])
+            rk, tk = sh.step_raw(ak)
+            assert torch.equal(rk.view(torch.int32), r[sl].view(torch.int32))
+            assert torch.equal(tk, tm[sl])
+    ef = full.export_boards()
+    for k, sh in enumerate(shards):
+        es = sh.export_boards()
+        sl = slice(k * (n // G), (k + 1) * (n // G))
+        for key in ef:
+            assert torch.equal(es[key], ef[key][sl]), key
+
+
+def test_empty_batch_and_argument_errors():
+    from qtttgym_amd import VecEnv, _native
+    env = VecEnv(0)
+    r, t = env.step_raw(torch.empty((0, 2), dtype=torch.uint8, device="cuda"))
+    assert r.numel() == 0 and t.numel() == 0
+    L = _native.lib()
+    assert L.qttt_reset(None, 5, None) == -1
+    assert L.qttt_reset(None, -1, None) == -2
+    assert L.qttt_state_bytes(1 << 20) == 20 << 20
+    env = VecEnv(4)
+    with pytest.raises(ValueError):
+        env.step_raw(torch.zeros((4, 2), dtype=torch.int64, device="cuda"))
+    with pytest.raises(_native.QtttNativeError):
+        VecEnv(4, device="cpu")
+
+
+def test_distribution_sanity_uniform_policy():
+    """T3: statistics of the uniform-legal policy at scale vs SURVEY.md §8d (measured on the
+    reference: mean episode length 8.30, collapse on 22.3 % of steps, autofill in 32.4 % of
+    episodes; outcomes P1-only 52.8 / both 22.2 / none 12.8 / P2-only 12.2 %)."""
+    from qtttgym_amd import VecEnv
+    n = 1 << 18
+    env = VecEnv(n, seed=9, auto_reset=False)
+    alive = torch.ones(n, dtype=torch.bool, device="cuda")
+    length = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for t in range(9):
+        a = env.sample_actions()
+        r, term = env.step_raw(a)
+        length += alive.to(torch.int32)
+        alive &= ~term
+    assert not bool(alive.any())
+    mean_len = float(length.float().mean())
+    assert abs(mean_len - 8.30) < 0.05, mean_len
