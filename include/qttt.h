@@ -13,7 +13,8 @@
  *   - illegal *actions* are data, not errors: they are noops exactly as env.py:36-43.
  *
  * State: an opaque device buffer of qttt_state_bytes(n) bytes for n boards (20 B/board,
- * structure-of-arrays: u64 plane A[n], u64 plane B[n], u32 plane C[n]).
+ * structure-of-arrays: u64 plane A[s], u64 plane B[s], u32 plane C[s], plane stride
+ * s = n rounded up to a multiple of 64).  16-byte aligned at least.
  */
 #ifndef QTTT_H
 #define QTTT_H
@@ -92,6 +93,11 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
 int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx,
                         int64_t board_offset, uint32_t flags, uint8_t *actions, int64_t n,
                         void *stream);
+
+/* Launch-shape knobs of qttt_step (results never depend on them): boards per lane (1, 2 or 4)
+ * and waves per SIMD of the persistent software-pipelined form (0 = one-shot grid).  Process-wide;
+ * also settable through QTTT_STEP_BPL / QTTT_STEP_PIPE before the first call. */
+int qttt_set_tuning(int boards_per_lane, int pipe_waves_per_simd);
 
 /* The counter hash itself (host-callable, no device work), so callers can reproduce bits. */
 uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx);

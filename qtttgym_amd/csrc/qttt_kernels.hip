@@ -25,12 +25,15 @@
 //   C : comps bits 0..31   (comps = 4 x 9-bit masks, slot k at bit 9k)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "qttt.h"
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define QTTT_BLOCK 256
+#define QTTT_DEFAULT_BPL 2
+#define QTTT_DEFAULT_PIPE 0
 
 namespace {
 
@@ -53,11 +56,15 @@ struct Planes {
     u32 *C;
 };
 
+// plane stride: n rounded up to 64 boards, so every plane starts 512-byte aligned
+__host__ __device__ inline int64_t plane_stride(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
 __host__ __device__ inline Planes planes(void *state, int64_t n) {
     Planes p;
+    const int64_t s = plane_stride(n);
     p.A = reinterpret_cast<u64 *>(state);
-    p.B = p.A + n;
-    p.C = reinterpret_cast<u32 *>(p.B + n);
+    p.B = p.A + s;
+    p.C = reinterpret_cast<u32 *>(p.B + s);
     return p;
 }
 
@@ -222,29 +229,159 @@ __device__ inline u32 step_board(Regs &r, u32 a, u32 b, u32 bit) {
 }
 
 // ------------------------------------------------------------------ kernels
-template <bool HAS_BITS, bool AUTO_RESET>
+// BPL boards per lane: lane j owns boards [j*BPL, (j+1)*BPL), so every plane is read and written
+// with 16-byte (or 2x16-byte) vector accesses that are contiguous across the wave, and the
+// fixed per-wave cost (dispatch, address setup, waits) is paid once per BPL boards.
+#ifdef QTTT_DEBUG_STAMPS
+__device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench --stamps)
+#endif
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+template <int BPL, bool HAS_BITS, bool AUTO_RESET>
 __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
     const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_lo,
     u64 board_offset, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
-    int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Regs r;
-    unpack(pA[i], pB[i], pC[i], r);
-    u32 act = actions[i];
-    u32 bit;
-    if (HAS_BITS) bit = bits[i] & 1u;
-    else bit = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo) >> 31;
-    u32 win = step_board<AUTO_RESET>(r, act & 0xFFu, act >> 8, bit);
-    u64 A, B;
-    u32 C;
-    pack(r, A, B, C);
-    pA[i] = A;
-    pB[i] = B;
-    pC[i] = C;
-    reward_bits[i] = win ? 0xBF800000u : 0x80000000u;            // env.py:49: -1.0f / -0.0f
-    terminated[i] = (uint8_t)r.done;
+    int64_t i_begin, int64_t n_groups) {
+    int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+#ifdef QTTT_DEBUG_STAMPS
+    const u64 st0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (j >= n_groups) return;
+    const int64_t i0 = i_begin + j * BPL;
+    typedef Vec<u64, BPL> V64;
+    typedef Vec<u32, BPL> V32;
+    typedef Vec<uint16_t, BPL> V16;
+    typedef Vec<uint8_t, BPL> V8;
+    V64 a = *reinterpret_cast<const V64 *>(pA + i0);
+    V64 b = *reinterpret_cast<const V64 *>(pB + i0);
+    V32 c = *reinterpret_cast<const V32 *>(pC + i0);
+    V16 act = *reinterpret_cast<const V16 *>(actions + i0);
+    V8 bt;
+    if (HAS_BITS) bt = *reinterpret_cast<const V8 *>(bits + i0);
+    V32 rw;
+    V8 tm;
+#ifdef QTTT_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        Regs r;
+        unpack(a.v[k], b.v[k], c.v[k], r);
+        u32 bit;
+        if (HAS_BITS) bit = bt.v[k] & 1u;
+        else bit = lowbias32(fold_id(board_offset + (u64)(i0 + k)) ^ key_lo) >> 31;
+        u32 av = act.v[k];
+        u32 win = step_board<AUTO_RESET>(r, av & 0xFFu, av >> 8, bit);
+        pack(r, a.v[k], b.v[k], c.v[k]);
+        rw.v[k] = win ? 0xBF800000u : 0x80000000u;               // env.py:49: -1.0f / -0.0f
+        tm.v[k] = (uint8_t)r.done;
+    }
+#ifdef QTTT_DEBUG_STAMPS
+    const u64 st2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    *reinterpret_cast<V64 *>(pA + i0) = a;
+    *reinterpret_cast<V64 *>(pB + i0) = b;
+    *reinterpret_cast<V32 *>(pC + i0) = c;
+    *reinterpret_cast<V32 *>(reward_bits + i0) = rw;
+    *reinterpret_cast<V8 *>(terminated + i0) = tm;
+#ifdef QTTT_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st3 = __builtin_amdgcn_s_memrealtime();
+    if (g_debug_stamps && (threadIdx.x & 63) == 0) {
+        u64 *o = g_debug_stamps + ((int64_t)blockIdx.x * (QTTT_BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+#endif
+}
+
+// Persistent, software-pipelined form of step_kernel: the grid is sized to a fixed number of
+// waves per SIMD and every lane walks lane-groups j, j+stride, ...; the loads of the NEXT group
+// are issued before the current group is computed, so a wave always has memory traffic in
+// flight while its VALU work runs, and waves drift out of phase instead of all loading, then all
+// computing, then all storing (measured: DESIGN.md §6).
+template <int BPL, bool HAS_BITS>
+struct Tile {
+    Vec<u64, BPL> a, b;
+    Vec<u32, BPL> c;
+    Vec<uint16_t, BPL> act;
+    Vec<uint8_t, BPL> bt;
+};
+
+template <int BPL, bool HAS_BITS, bool AUTO_RESET>
+__global__ __launch_bounds__(QTTT_BLOCK) void step_kernel_pipe(
+    u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
+    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_lo,
+    u64 board_offset, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    int64_t n_groups) {
+    const int64_t stride = (int64_t)gridDim.x * QTTT_BLOCK;
+    int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (j >= n_groups) return;
+    typedef Vec<u64, BPL> V64;
+    typedef Vec<u32, BPL> V32;
+    typedef Vec<uint16_t, BPL> V16;
+    typedef Vec<uint8_t, BPL> V8;
+    Tile<BPL, HAS_BITS> cur, nxt;
+    auto load = [&](Tile<BPL, HAS_BITS> &t, int64_t g) {
+        const int64_t i0 = g * BPL;
+        t.a = *reinterpret_cast<const V64 *>(pA + i0);
+        t.b = *reinterpret_cast<const V64 *>(pB + i0);
+        t.c = *reinterpret_cast<const V32 *>(pC + i0);
+        t.act = *reinterpret_cast<const V16 *>(actions + i0);
+        if (HAS_BITS) t.bt = *reinterpret_cast<const V8 *>(bits + i0);
+    };
+    auto process = [&](Tile<BPL, HAS_BITS> &t, int64_t g) {
+        const int64_t i0 = g * BPL;
+        V32 rw;
+        V8 tm;
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            Regs r;
+            unpack(t.a.v[k], t.b.v[k], t.c.v[k], r);
+            u32 bit;
+            if (HAS_BITS) bit = t.bt.v[k] & 1u;
+            else bit = lowbias32(fold_id(board_offset + (u64)(i0 + k)) ^ key_lo) >> 31;
+            u32 av = t.act.v[k];
+            u32 win = step_board<AUTO_RESET>(r, av & 0xFFu, av >> 8, bit);
+            pack(r, t.a.v[k], t.b.v[k], t.c.v[k]);
+            rw.v[k] = win ? 0xBF800000u : 0x80000000u;
+            tm.v[k] = (uint8_t)r.done;
+        }
+        *reinterpret_cast<V64 *>(pA + i0) = t.a;
+        *reinterpret_cast<V64 *>(pB + i0) = t.b;
+        *reinterpret_cast<V32 *>(pC + i0) = t.c;
+        *reinterpret_cast<V32 *>(reward_bits + i0) = rw;
+        *reinterpret_cast<V8 *>(terminated + i0) = tm;
+    };
+    // Ping-pong between two register tiles (no copies).  The first tile is peeled so that both
+    // ways into the loop header carry the same outstanding-memory-op pattern (4 loads, then the
+    // previous tile's 5 stores); otherwise the compiler's merged s_waitcnt makes every tile wait
+    // for the previous tile's stores.  Prefetches are unconditional (clamped index) for the same
+    // reason: a branch around them merges to "wait for everything".
+    int64_t j1 = j + stride;
+    bool more = j1 < n_groups;
+    load(cur, j);
+    load(nxt, more ? j1 : j);
+    process(cur, j);
+    if (!more) return;
+    for (;;) {
+        const int64_t j2 = j1 + stride;
+        const bool m2 = j2 < n_groups;
+        load(cur, m2 ? j2 : j1);
+        process(nxt, j1);
+        if (!m2) break;
+        const int64_t j3 = j2 + stride;
+        const bool m3 = j3 < n_groups;
+        load(nxt, m3 ? j3 : j2);
+        process(cur, j2);
+        if (!m3) break;
+        j1 = j3;
+    }
 }
 
 __global__ __launch_bounds__(QTTT_BLOCK) void reset_kernel(u64 *pA, u64 *pB, u32 *pC, int64_t n) {
@@ -438,6 +575,25 @@ __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     actions[i * 2 + 1] = (uint8_t)hi;
 }
 
+// tuning knobs (bench / profiling): boards per lane (1|2|4) and, for the persistent pipelined
+// form, waves per SIMD (0 = plain one-shot grid).  Initialised from QTTT_STEP_BPL /
+// QTTT_STEP_PIPE, changeable at run time through qttt_set_tuning().
+struct Tuning {
+    int bpl;
+    int pipe;
+};
+inline Tuning &tuning() {
+    static Tuning t = [] {
+        Tuning v{QTTT_DEFAULT_BPL, QTTT_DEFAULT_PIPE};
+        if (const char *e = getenv("QTTT_STEP_BPL")) { int k = atoi(e); if (k == 1 || k == 2 || k == 4) v.bpl = k; }
+        if (const char *e = getenv("QTTT_STEP_PIPE")) { int k = atoi(e); if (k >= 0 && k <= 8) v.pipe = k; }
+        return v;
+    }();
+    return t;
+}
+inline int step_bpl_override() { return tuning().bpl; }
+inline int step_pipe_override() { return tuning().pipe; }
+
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
 
 inline int launch_status() {
@@ -452,7 +608,22 @@ extern "C" {
 
 int qttt_abi_version(void) { return QTTT_ABI_VERSION; }
 
-int64_t qttt_state_bytes(int64_t n) { return n < 0 ? (int64_t)QTTT_ERR_SIZE : n * 20; }
+#ifdef QTTT_DEBUG_STAMPS
+int qttt_debug_set_stamps(void *buf) {
+    u64 *p = (u64 *)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_debug_stamps), &p, sizeof(p));
+}
+#endif
+
+int qttt_set_tuning(int boards_per_lane, int pipe_waves_per_simd) {
+    if (!(boards_per_lane == 1 || boards_per_lane == 2 || boards_per_lane == 4)) return QTTT_ERR_SIZE;
+    if (pipe_waves_per_simd < 0 || pipe_waves_per_simd > 8) return QTTT_ERR_SIZE;
+    tuning().bpl = boards_per_lane;
+    tuning().pipe = pipe_waves_per_simd;
+    return 0;
+}
+
+int64_t qttt_state_bytes(int64_t n) { return n < 0 ? (int64_t)QTTT_ERR_SIZE : plane_stride(n) * 20; }
 
 uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx) {
     u64 key = launch_key(seed, step_idx);
@@ -483,18 +654,53 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are read as u16 pairs
     Planes p = planes(state, n);
     u32 key_lo = (u32)launch_key(seed, step_idx);
-    dim3 g(grid_for(n)), b(QTTT_BLOCK);
     hipStream_t s = (hipStream_t)stream;
     const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
     u32 *rb = reinterpret_cast<u32 *>(reward);
-    bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
-    if (bits) {
-        if (ar) hipLaunchKernelGGL((step_kernel<true, true>), g, b, 0, s, p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated, n);
-        else    hipLaunchKernelGGL((step_kernel<true, false>), g, b, 0, s, p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated, n);
-    } else {
-        if (ar) hipLaunchKernelGGL((step_kernel<false, true>), g, b, 0, s, p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated, n);
-        else    hipLaunchKernelGGL((step_kernel<false, false>), g, b, 0, s, p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated, n);
+    const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
+    // widest boards-per-lane the caller's pointers are aligned for (planes always are)
+    int bpl = step_bpl_override();
+    auto aligned = [&](int k) {
+        return ((uintptr_t)actions % (2u * k)) == 0 && ((uintptr_t)reward % (4u * k)) == 0 &&
+               ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
+    };
+    while (bpl > 1 && !aligned(bpl)) bpl >>= 1;
+    const int64_t n_groups = n / bpl, n_main = n_groups * bpl;
+#define QTTT_LAUNCH(BPL, HB, AR, I0, NG)                                                        \
+    hipLaunchKernelGGL((step_kernel<BPL, HB, AR>), dim3(grid_for(NG)), dim3(QTTT_BLOCK), 0, s,  \
+                       p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated,     \
+                       (int64_t)(I0), (int64_t)(NG))
+#define QTTT_DISPATCH(BPL, I0, NG)                                   \
+    do {                                                             \
+        if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, I0, NG); else QTTT_LAUNCH(BPL, true, false, I0, NG); } \
+        else      { if (ar) QTTT_LAUNCH(BPL, false, true, I0, NG); else QTTT_LAUNCH(BPL, false, false, I0, NG); } \
+    } while (0)
+    const int pipe = step_pipe_override();      // waves per SIMD of the persistent form, 0 = off
+    if (n_groups > 0 && pipe > 0) {
+        int64_t blocks = (n_groups + QTTT_BLOCK - 1) / QTTT_BLOCK;
+        const int64_t cap = (int64_t)256 * pipe;  // 256 CUs x (pipe waves/SIMD x 4 SIMDs / 4 waves per block)
+        if (blocks > cap) blocks = cap;
+#define QTTT_LAUNCH_P(BPL, HB, AR)                                                               \
+    hipLaunchKernelGGL((step_kernel_pipe<BPL, HB, AR>), dim3((unsigned)blocks), dim3(QTTT_BLOCK), 0, s, \
+                       p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated, n_groups)
+#define QTTT_DISPATCH_P(BPL)                                          \
+    do {                                                              \
+        if (bits) { if (ar) QTTT_LAUNCH_P(BPL, true, true); else QTTT_LAUNCH_P(BPL, true, false); } \
+        else      { if (ar) QTTT_LAUNCH_P(BPL, false, true); else QTTT_LAUNCH_P(BPL, false, false); } \
+    } while (0)
+        if (bpl == 4) QTTT_DISPATCH_P(4);
+        else if (bpl == 2) QTTT_DISPATCH_P(2);
+        else QTTT_DISPATCH_P(1);
+#undef QTTT_DISPATCH_P
+#undef QTTT_LAUNCH_P
+    } else if (n_groups > 0) {
+        if (bpl == 4) QTTT_DISPATCH(4, 0, n_groups);
+        else if (bpl == 2) QTTT_DISPATCH(2, 0, n_groups);
+        else QTTT_DISPATCH(1, 0, n_groups);
     }
+    if (n_main < n) QTTT_DISPATCH(1, n_main, n - n_main);        // ragged tail, one board per lane
+#undef QTTT_DISPATCH
+#undef QTTT_LAUNCH
     return launch_status();
 }
 
