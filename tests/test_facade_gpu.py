@@ -1,0 +1,147 @@
+"""The reference's single-board surface (`Env`, `Board`, `QEvalClassic`) on top of the HIP
+library, checked against the golden traces: same Python types, same aliasing, same exceptions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Bits:
+    """Stands in for the `random` module inside qtttgym_amd.board (the one draw of qeval.py:35)."""
+
+    def __init__(self):
+        self.bit = 0
+        self.calls = 0
+
+    def choice(self, seq):
+        self.calls += 1
+        return seq[self.bit]
+
+
+@pytest.fixture()
+def bits(monkeypatch):
+    import qtttgym_amd.board as board_mod
+    b = Bits()
+    monkeypatch.setattr(board_mod, "random", b)
+    return b
+
+
+def test_env_matches_golden_python_types(golden, bits):
+    from qtttgym_amd import Env
+    kinds = list(golden["kind"])
+    picks = [i for i, k in enumerate(kinds) if k.startswith("K")]
+    picks += [i for i, k in enumerate(kinds) if k == "uniform"][:40]
+    picks += [i for i, k in enumerate(kinds) if k == "adversarial"][:40]
+    T = golden["bits"].shape[1]
+    for e in picks:
+        env = Env()
+        obs, info = env.reset()
+        assert info == {} and obs["classical"] == [-1] * 9 and obs["turn"] == 0
+        classical_alias = obs["classical"]
+        for t in range(T):
+            bits.bit = int(golden["bits"][e, t])
+            calls = bits.calls
+            a, b = (int(x) for x in golden["actions"][e, t])
+            obs, r, term, trunc, info = env.step((a, b))
+            assert isinstance(r, float) and isinstance(term, bool) and trunc is False and info == {}
+            assert bits.calls - calls == int(golden["consumed"][e, t])
+            assert obs["classical"] is classical_alias                 # env.py:71,82 aliasing
+            assert obs["classical"] == golden["board"][e, t].tolist()
+            n1, n2 = int(golden["q_p1_len"][e, t]), int(golden["q_p2_len"][e, t])
+            assert obs["q_states_p1"] == [tuple(x) for x in golden["q_p1"][e, t, :n1].tolist()]
+            assert obs["q_states_p2"] == [tuple(x) for x in golden["q_p2"][e, t, :n2].tolist()]
+            assert obs["turn"] == int(golden["turn"][e, t])
+            assert np.float64(r).view(np.uint64) == golden["reward"][e, t].view(np.uint64)   # -0.0
+            assert term == bool(golden["terminated"][e, t])
+            assert env.turn() == int(golden["n_moves"][e, t])
+            gb = env._gameboard
+            nm = int(golden["n_moves"][e, t])
+            assert gb.moves == [(int(golden["moves"][e, t, i, 0]), int(golden["moves"][e, t, i, 1]), i)
+                                for i in range(nm)]
+            nq = int(golden["n_q"][e, t])
+            assert gb.qstructs == [set(s for s in range(9) if int(golden["qmask"][e, t, i]) >> s & 1)
+                                   for i in range(nq)]
+            assert gb.check_win() == (int(golden["p1_round"][e, t]), int(golden["p2_round"][e, t]))
+
+
+def test_board_exceptions_and_no_mutation(bits):
+    from qtttgym_amd import Board, QEvalClassic
+    b = Board(QEvalClassic())
+    with pytest.raises(Exception, match="Move in same square not allowed when not necessary"):
+        b.make_move((4, 4))
+    b.make_move((1, 0))
+    assert b.moves == [(0, 1, 0)] and b.qstructs == [{0, 1}]
+    bits.bit = 1
+    b.make_move((0, 1))
+    assert b.board[:2] == [0, 1] and b.qstructs == []
+    snapshot = (list(b.board), list(b.moves), list(b.qstructs))
+    with pytest.raises(Exception, match="Move in classical square not allowed"):
+        b.make_move((0, 5))
+    with pytest.raises(IndexError):
+        b.make_move((9, 5))
+    assert (b.board, b.moves, b.qstructs) == snapshot
+
+
+def test_l3_style_subclass_assigning_attributes(bits):
+    """mcts.py:9-17,235-242: subclass Board, assign .board/.moves/.qstructs, then make_move."""
+    from qtttgym_amd import Board, QEvalClassic
+
+    class GameState(Board):
+        def __init__(self, board, moves):
+            Board.__init__(self, QEvalClassic())
+            self.board = board
+            self.moves = moves
+
+    parent = GameState([-1] * 9, [])
+    for mv in [(4, 6), (1, 2), (1, 8), (0, 2)]:           # K7 prefix
+        parent.make_move(mv)
+    child = GameState(parent.board.copy(), parent.moves.copy())
+    child.qstructs = [set(s) for s in parent.qstructs]
+    bits.bit = 1
+    child.make_move((4, 6))
+    assert child.board == [-1, -1, -1, -1, 0, -1, 4, -1, -1]
+    assert parent.board == [-1] * 9                          # parent untouched
+    child.make_move((0, 2))
+    assert child.board == [3, 1, 5, -1, 0, -1, 4, -1, 2]
+    assert child.check_win() == (-1, 5)
+
+
+def test_qevalclassic_eval_standalone(bits):
+    from qtttgym_amd import QEvalClassic
+    q = QEvalClassic()
+    bits.bit = 0
+    assert q.eval([(0, 1, 0), (0, 1, 1)]) == [1, 0]          # K1
+    bits.bit = 1
+    assert q.eval([(0, 1, 0), (0, 1, 1)]) == [0, 1]          # K2
+    # K3: 3-cycle 1-2-3 with tail 0-1, closing move (1,3) lands on 3
+    assert q.eval([(0, 1, 0), (1, 2, 1), (2, 3, 2), (1, 3, 3)]) == [0, 1, 2, 3]
+
+
+def test_custom_evaluator_plug_point():
+    """board.py:2,7,51: any object with .eval(list) decides the collapse."""
+    from qtttgym_amd import Board
+
+    class FirstSquare:
+        def __init__(self):
+            self.seen = None
+
+        def eval(self, entangled):
+            self.seen = list(entangled)
+            return [1, 0]
+
+    ev = FirstSquare()
+    b = Board(ev)
+    b.make_move((0, 1))
+    b.make_move((0, 1))
+    assert ev.seen == [(0, 1, 0), (0, 1, 1)]
+    assert b.board[:2] == [1, 0] and b.qstructs == []
+
+
+def test_vecenv_render_and_turn(capsys):
+    from qtttgym_amd import VecEnv
+    import torch
+    env = VecEnv(3)
+    env.step(torch.tensor([[0, 1], [2, 2], [4, 8]], dtype=torch.uint8))
+    assert env.turn().tolist() == [1, 0, 1]
+    env.render(2)
+    assert "+---+---+---+" in capsys.readouterr().out

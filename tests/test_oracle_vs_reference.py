@@ -1,0 +1,95 @@
+"""Live fuzz of the C oracle against the UNMODIFIED reference imported from /root/reference
+(build container only; skipped on the GPU box where the reference does not exist).  Fresh
+random episodes every run-independent seed list, far more than the committed fixtures hold."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from ref_shim import load_reference, reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="reference not present")
+
+
+def _play(qtttgym, src, rng, n_eps, T, adversarial):
+    acts = np.zeros((n_eps, T, 2), dtype=np.uint8)
+    bits = np.zeros((n_eps, T), dtype=np.uint8)
+    exp = {k: [] for k in ("board", "n_moves", "moves", "qmask", "n_q", "reward", "term", "p1", "p2")}
+    for e in range(n_eps):
+        env = qtttgym.Env()
+        env.reset()
+        rows = {k: [] for k in exp}
+        for t in range(T):
+            board = env._gameboard.board
+            empty = [i for i in range(9) if board[i] == -1]
+            if adversarial and rng.random() < 0.4 or len(empty) < 2:
+                a, b = rng.randrange(0, 12), rng.randrange(0, 12)
+            else:
+                a, b = rng.sample(empty, 2)
+            bit = rng.getrandbits(1)
+            src.bit = bit
+            obs, r, term, trunc, info = env.step((a, b))
+            acts[e, t] = (a, b)
+            bits[e, t] = bit
+            gb = env._gameboard
+            rows["board"].append(list(gb.board))
+            rows["n_moves"].append(len(gb.moves))
+            mv = [[255, 255]] * 9
+            for i, m in enumerate(gb.moves):
+                mv[i] = [m[0], m[1]]
+            rows["moves"].append(mv)
+            qm = [0] * 4
+            for i, s in enumerate(gb.qstructs):
+                qm[i] = sum(1 << x for x in s)
+            rows["qmask"].append(qm)
+            rows["n_q"].append(len(gb.qstructs))
+            rows["reward"].append(r)
+            rows["term"].append(bool(term))
+            p1, p2 = gb.check_win()
+            rows["p1"].append(p1)
+            rows["p2"].append(p2)
+        for k in exp:
+            exp[k].append(rows[k])
+    return acts, bits, {k: np.array(v) for k, v in exp.items()}
+
+
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_oracle_vs_reference_live(adversarial):
+    qtttgym, src = load_reference()
+    rng = random.Random(9001 + adversarial)
+    n_eps, T = 3000, 12
+    acts, bits, exp = _play(qtttgym, src, rng, n_eps, T, adversarial)
+    ob = oracle.OracleBoards(n_eps)
+    for t in range(T):
+        reward, term = ob.step(acts[:, t], bits[:, t])
+        assert np.array_equal(ob.board, exp["board"][:, t].astype(np.int8))
+        assert np.array_equal(ob.n_moves, exp["n_moves"][:, t].astype(np.uint8))
+        assert np.array_equal(ob.moves, exp["moves"][:, t].astype(np.uint8))
+        assert np.array_equal(ob.qmask, exp["qmask"][:, t].astype(np.uint16))
+        assert np.array_equal(ob.n_q, exp["n_q"][:, t].astype(np.uint8))
+        assert np.array_equal(reward.view(np.uint32),
+                              exp["reward"][:, t].astype(np.float32).view(np.uint32))
+        assert np.array_equal(term, exp["term"][:, t].astype(np.uint8))
+        p1, p2 = ob.check_win()
+        assert np.array_equal(p1, exp["p1"][:, t].astype(np.int8))
+        assert np.array_equal(p2, exp["p2"][:, t].astype(np.int8))
+
+
+def test_reference_draws_one_bit_per_collapse_only():
+    """random.choice is called exactly once per collapse with (lo, hi)."""
+    qtttgym, src = load_reference()
+    rng = random.Random(5)
+    for _ in range(300):
+        env = qtttgym.Env()
+        env.reset()
+        for t in range(10):
+            board = env._gameboard.board
+            empty = [i for i in range(9) if board[i] == -1]
+            if len(empty) < 2:
+                break
+            before = list(board)
+            calls = src.calls
+            env.step(tuple(rng.sample(empty, 2)))
+            collapsed = before != env._gameboard.board
+            assert src.calls - calls == (1 if collapsed else 0)
