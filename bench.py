@@ -25,6 +25,20 @@ if ROOT not in sys.path:
 STATE_BYTES = 20          # packed state per board
 ALGO_BYTES_PER_STEP = 2 * STATE_BYTES + 2 + 4 + 1   # state r+w, action, reward f32, terminated
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def pmc_traffic_per_launch(boards):
+    """HBM bytes per step launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction in
+    MI355X_MICROARCH.md §HBM).  None if no summary for this batch size is committed."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
+        e = d.get(str(boards))
+        return None if e is None else float(e["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(actions_host, seed, budget_s=12.0):
@@ -35,7 +49,7 @@ def cpu_baseline(actions_host, seed, budget_s=12.0):
     from concurrent.futures import ThreadPoolExecutor
     import oracle
     T, n = actions_host.shape[0], actions_host.shape[1]
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    cores = max(1, min(os.cpu_count() or 1, 16))   # the GPU box's CPU share for one GPU
     per = n // cores
     boards = [oracle.OracleBoards(per) for _ in range(cores)]
 
@@ -159,14 +173,14 @@ def main():
                        "replay_matches_recording": replay_ok,
                        "episodes_finished": int(term_count), "steps_with_line": int(win_count)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(B),
                          "kernel": "step_kernel<false,true>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * B},
         }
         if not args.no_cpu_baseline:
-            n_cpu = min(B, 1 << 18)
-            t_cpu = min(T, 64)
-            out["cpu_baseline"] = cpu_baseline(actions[:t_cpu, :n_cpu].cpu().numpy(), args.seed)
+            # bounded sample: the first <=256 recorded steps of every board of rank 0
+            t_cpu = min(T, 256)
+            out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
