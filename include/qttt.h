@@ -94,10 +94,9 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx,
                         int64_t board_offset, uint32_t flags, uint8_t *actions, int64_t n,
                         void *stream);
 
-/* Launch-shape knobs of qttt_step (results never depend on them): boards per lane (1, 2 or 4)
- * and waves per SIMD of the persistent software-pipelined form (0 = one-shot grid).  Process-wide;
- * also settable through QTTT_STEP_BPL / QTTT_STEP_PIPE before the first call. */
-int qttt_set_tuning(int boards_per_lane, int pipe_waves_per_simd);
+/* Launch-shape knob of qttt_step (results never depend on it): boards per lane (1, 2 or 4).
+ * Process-wide; also settable through QTTT_STEP_BPL before the first call.  `reserved` = 0. */
+int qttt_set_tuning(int boards_per_lane, int reserved);
 
 /* The counter hash itself (host-callable, no device work), so callers can reproduce bits. */
 uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx);

@@ -1,9 +1,11 @@
 // qttt_kernels.hip — gfx950 (MI355X / CDNA4) kernels + the C ABI of include/qttt.h.
 //
-// Mapping: ONE LANE PER BOARD (64 boards per wavefront), everything in VGPRs, structure-of-
-// arrays state so that every load/store of a wave is one contiguous, fully coalesced segment.
-// No LDS, no MFMA: the path is HBM-bound integer/bit work (DESIGN.md §2 explains why the
-// wave-per-board mapping was rejected after measurement).
+// Mapping: ONE LANE PER BOARD (64 boards per wavefront, BPL consecutive boards per lane),
+// everything in VGPRs, structure-of-arrays state so that every load/store of a wave is one
+// contiguous 16-byte-per-lane segment.  No MFMA; LDS holds one 512-byte lookup table.
+// DESIGN.md §2 explains why the wave-per-board mapping was rejected after measurement and why
+// the kernel is written for minimum VALU *instruction count* (measured issue cost ~4 cycles per
+// wave-instruction for this instruction mix, tools/valu_rates.cpp).
 //
 // Formulation — deliberately NOT the reference's algorithm:
 //   * the un-collapsed moves of a board form a forest on the 9 squares (a move that closes a
@@ -18,11 +20,18 @@
 //   * Board.qstructs (board.py:6) is cached as 4 slots x 9-bit square masks, in the reference's
 //     list order, so "same component?" is two shifts and an AND.
 //
-// Packed state, 20 B/board, planes A[n] u64 | B[n] u64 | C[n] u32:
-//   A : moves 0..7, byte i = lo | hi<<4 (board.py:19), unused bytes 0
-//   B : [0,36) sq nibbles | [36,44) move 8 | [44,48) n_moves | [48,57) classical mask |
-//       57 done (terminated at the end of the last step) | [60,64) comps bits 32..35
-//   C : comps bits 0..31   (comps = 4 x 9-bit masks, slot k at bit 9k)
+// Packed state, 20 B/board, planes A[s] u64 | B[s] u64 | C[s] u32 (s = n rounded up to 64):
+//   A : move queue, newest move in byte 0: the move of round t sits in byte n-1-t
+//       (byte = lo | hi<<4, board.py:19); a 9th entry (only round 0, only when n == 9)
+//       spills into B's `mv8` field.  Unused bytes are 0.
+//   B : bits [0,36) sq nibbles, stored COMPLEMENTED (nibble ^ 0xF, so 0 = root / isolated) |
+//       [36,44) mv8 | [44,48) n = number of moves PLAYED | [48,57) classical mask |
+//       [57,61) comps bits 32..35 | 61,62 zero | 63 done (terminated after the last step)
+//   C : comps bits 0..31   (comps = 4 x 9-bit masks, slot k at bit 9k, list order, compact)
+//   The all-zero state is the empty board, so reset is a memset.
+//   The autofill of board.py:22-25 is IMPLICIT: a board with exactly 8 classical squares stands
+//   for the reference state in which the 9th square holds round 8 and moves ends with (idx,idx,8)
+//   (the autofill round is always 8); the cold kernels materialise it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -33,22 +42,14 @@ typedef unsigned int u32;
 
 #define QTTT_BLOCK 256
 #define QTTT_DEFAULT_BPL 2
-#define QTTT_DEFAULT_PIPE 0
 
 namespace {
 
-constexpr u64 SQ_EMPTY = 0xFFFFFFFFFull;   // nine 0xF nibbles
 constexpr u32 SLOT_LSB = 0x08040201u;      // bit 0 of each 9-bit comps slot
 
-struct Regs {
-    u64 A;      // moves 0..7
-    u64 sq;     // 9 nibbles
-    u64 comps;  // 4 x 9 bits
-    u32 mv8;    // move 8
-    u32 n;      // n_moves
-    u32 cl;     // classical mask
-    u32 done;   // cached terminated flag
-};
+// B1 = high word of plane B
+constexpr u32 B1_MV8_SHIFT = 4, B1_N_SHIFT = 12, B1_CL_SHIFT = 16, B1_CHI_SHIFT = 25;
+constexpr u32 B1_DONE = 0x80000000u;
 
 struct Planes {
     u64 *A;
@@ -68,228 +69,220 @@ __host__ __device__ inline Planes planes(void *state, int64_t n) {
     return p;
 }
 
-__device__ inline void unpack(u64 A, u64 B, u32 C, Regs &r) {
-    u32 hi = (u32)(B >> 32);
-    r.A = A;
-    r.sq = B & SQ_EMPTY;
-    r.mv8 = (hi >> 4) & 0xFFu;
-    r.n = (hi >> 12) & 0xFu;
-    r.cl = (hi >> 16) & 0x1FFu;
-    r.done = (hi >> 25) & 1u;
-    r.comps = (u64)C | ((u64)(hi >> 28) << 32);
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+#ifdef QTTT_DEBUG_STAMPS
+__device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench stamps)
+#endif
+
+// ------------------------------------------------------------------ 3-in-a-row lookup table
+// line_lut[m] = 0x7F iff the 9-bit square mask m contains one of the 8 lines of board.py:85-110.
+__host__ __device__ constexpr bool mask_has_line(u32 m) {
+    return (m & 0x007u) == 0x007u || (m & 0x038u) == 0x038u || (m & 0x1C0u) == 0x1C0u ||
+           (m & 0x049u) == 0x049u || (m & 0x092u) == 0x092u || (m & 0x124u) == 0x124u ||
+           (m & 0x054u) == 0x054u || (m & 0x111u) == 0x111u;
 }
 
-__device__ inline void pack(const Regs &r, u64 &A, u64 &B, u32 &C) {
-    u32 chi = (u32)(r.comps >> 32);
-    u32 hi = (u32)(r.sq >> 32) | (r.mv8 << 4) | (r.n << 12) | (r.cl << 16) | (r.done << 25) |
-             (chi << 28);
-    A = r.A;
-    B = (u64)(u32)r.sq | ((u64)hi << 32);
-    C = (u32)r.comps;
-}
+struct LineLut {
+    uint8_t b[512];
+    constexpr LineLut() : b() {
+        for (u32 m = 0; m < 512; ++m) b[m] = mask_has_line(m) ? 0x7F : 0;   // 0x7F << 23 = 1.0f
+    }
+};
+__constant__ LineLut g_line_lut = LineLut();
 
-__device__ inline void regs_reset(Regs &r) {
-    r.A = 0;
-    r.sq = SQ_EMPTY;
-    r.comps = 0;
-    r.mv8 = 0;
-    r.n = 0;
-    r.cl = 0;
-    r.done = 0;
-}
-
-__device__ inline u32 get_move(const Regs &r, u32 idx) {
-    u32 m = (u32)(r.A >> ((idx & 7u) * 8u)) & 0xFFu;
-    return idx >= 8u ? r.mv8 : m;
-}
-
-__device__ inline void append_move(Regs &r, u32 idx, u32 mv) {
-    if (idx >= 8u) r.mv8 = mv;
-    else r.A |= (u64)mv << (idx * 8u);
-}
-
-__device__ inline u32 get_sq(const Regs &r, u32 v) { return (u32)(r.sq >> (v * 4u)) & 0xFu; }
-
-// drop the 9-bit slot that starts at bit `s` and close the gap (list.pop, board.py:56,61)
-__device__ inline u64 comps_pop(u64 comps, u32 s) {
-    u64 low = (1ull << s) - 1ull;
-    return (comps & low) | ((comps >> 9) & ~low);
-}
-
-// 9-bit mask of the squares whose sq nibble is odd
-__device__ inline u32 odd_mask(u64 sq) {
-    u32 x = (u32)sq & 0x11111111u;
-    // 4 nibble-LSBs -> 4 adjacent bits: (x & 0x1111) * 0x249 puts bit 4i at 9+i, no carries
-    u32 lo = (__umul24(x & 0x1111u, 0x249u) >> 9) & 0xFu;
-    u32 hi = (__umul24(x >> 16, 0x249u) >> 9) & 0xFu;
-    return lo | (hi << 4) | (((u32)(sq >> 32) & 1u) << 8);
-}
-
-// any completed 3-in-a-row in X (bits 0..8) or O (bits 16..24) of w
-__device__ inline u32 any_line(u32 w) {
-    u32 rows = w & (w >> 1) & (w >> 2) & 0x00490049u;
-    u32 cols = w & (w >> 3) & (w >> 6) & 0x00070007u;
-    u32 diag = w & (w >> 4) & (w >> 8) & 0x00010001u;
-    u32 anti = (w >> 2) & (w >> 4) & (w >> 6) & 0x00010001u;
-    return rows | cols | diag | anti;
-}
-
-__device__ inline u32 lowbias32(u32 x) {
+// ------------------------------------------------------------------ counter hash (the build's
+// synthetic-input spec)
+__host__ __device__ inline u32 lowbias32(u32 x) {
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
     return x;
 }
-
 __host__ __device__ inline u64 splitmix64(u64 x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-
 __host__ __device__ inline u64 launch_key(u64 seed, u32 step_idx) {
     return splitmix64(seed ^ ((u64)step_idx * 0xD1B54A32D192ED03ull));
 }
-
 __host__ __device__ inline u32 fold_id(u64 board_id) {
-    return (u32)board_id ^ ((u32)(board_id >> 32) * 0x9E3779B9u);
+    u32 f = (u32)board_id;
+    u32 h = (u32)(board_id >> 32);
+    if (h) f ^= h * 0x9E3779B9u;           // never taken below 2^32 boards: no multiply on the hot path
+    return f;
+}
+// top bit of lowbias32(x): the final xor-shift cannot change bit 31, so it is skipped
+__device__ inline u32 collapse_bit_of(u32 x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    return x >> 31;
 }
 
-// One Env.step on the board in registers.  Returns non-zero iff a line exists afterwards.
+// ====================================================================== the hot path
+// One Env.step (env.py:34-53) on the board held in (A0,A1,B0,B1,C).  `lut` is the LDS copy of
+// g_line_lut.  Returns 0x7F iff a completed line exists afterwards (else 0); B1's done bit is
+// updated.
 template <bool AUTO_RESET>
-__device__ inline u32 step_board(Regs &r, u32 a, u32 b, u32 bit) {
-    if (AUTO_RESET) {
-        if (r.done) regs_reset(r);
+__device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32 &C, u32 act, u32 bit,
+                                         const uint8_t *lut) {
+    if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
+        const u32 keep = ~(u32)((int)B1 >> 31);         // 0 iff done
+        A0 &= keep;
+        A1 &= keep;
+        B0 &= keep;
+        B1 &= keep;
+        C &= keep;
     }
-    u32 lo = min(a, b), hi = max(a, b);
-    // board.py:10-15 (+ IndexError for >8, env.py:41): reject before mutating anything
-    u32 lo_c = lo & 15u, hi_c = hi & 15u;
-    bool valid = (hi < 9u) && (lo != hi) && (((r.cl >> lo_c) | (r.cl >> hi_c)) & 1u) == 0u;
-    if (valid) {
-        const u32 n = r.n;
-        append_move(r, n, lo | (hi << 4));                       // board.py:19
-        u32 n1 = n + 1u;
-        u32 mlo = (u32)(r.comps >> lo) & SLOT_LSB;               // slot holding lo (board.py:28-33)
-        u32 mhi = (u32)(r.comps >> hi) & SLOT_LSB;               // slot holding hi (board.py:35-40)
-        u32 both = mlo & mhi;
-        bool cyc = both != 0u;                                   // board.py:42
-        // x: the square that becomes the child end of the new edge.  On a cycle it is the
-        // square the closing move lands on (qeval.py:35), which becomes the root.
-        u32 x = cyc ? (bit ? hi : lo) : hi;
-        {   // re-root x's tree at x: reverse parent edges along the path x -> old root
-            u32 v = x, prev = 0xFu;
+    const u32 a = act & 0xFFu, b = act >> 8;            // action[0], action[1] (env.py:37-38)
+    const u32 lo = min(a, b), hi = max(a, b);           // board.py:16-18
+    const u32 pm = (1u << (lo & 31u)) | (1u << (hi & 31u));
+    const u32 cl0 = (B1 >> B1_CL_SHIFT) & 0x1FFu;
+    // board.py:10-15 (+ IndexError for >8, swallowed at env.py:41): reject before mutating
+    if (hi < 9u && lo != hi && (pm & cl0) == 0u) {
+        const u32 n = (B1 >> B1_N_SHIFT) & 0xFu;
+        u64 comps = (u64)C | ((u64)((B1 >> B1_CHI_SHIFT) & 0xFu) << 32);
+        const u32 mlo = (u32)(comps >> lo) & SLOT_LSB;   // slot holding lo (board.py:28-33)
+        const u32 mhi = (u32)(comps >> hi) & SLOT_LSB;   // slot holding hi (board.py:35-40)
+        const bool has_lo = mlo != 0u, has_hi = mhi != 0u;
+        const bool cyc = (mlo & mhi) != 0u;              // board.py:42: same component -> cycle
+        // x: the square that becomes the child end of the new edge; on a cycle it is the square
+        // the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi), which becomes the root
+        const u32 x4 = ((cyc && bit == 0u) ? lo : hi) * 4u;
+        u64 B = (u64)B0 | ((u64)B1 << 32);               // sq nibbles (complemented) = bits 0..35
+        {   // re-root x's tree at x: reverse the parent edges along the path x -> old root.
+            // XB byte q = (lo^hi)*4 of queue entry q, so "other end of edge e" is one v_perm + xor.
+            // The queue index of round e is n-1-e = ec - (16-n) for the stored ec = e^15; adding ec
+            // to 0x0C0C0C00-(16-n) always carries out of byte 0, leaving selector bytes 1..3 = 0x0C
+            // (constant zero) and byte 0 = the queue index.
+            const u64 A = (u64)A0 | ((u64)A1 << 32);
+            const u64 XB = ((A ^ (A >> 4)) & 0x0F0F0F0F0F0F0F0Full) << 2;
+            const u32 XB0 = (u32)XB, XB1 = (u32)(XB >> 32);
+            const u32 base = 0x0C0C0BF0u + n;
+            u32 v4 = x4, prev = 0u;
+#pragma unroll
             for (int i = 0; i < 9; ++i) {
-                u32 sh = v * 4u;
-                u32 e = (u32)(r.sq >> sh) & 0xFu;
-                r.sq ^= (u64)(e ^ prev) << sh;                   // sq[v] = prev
-                if (e == 0xFu) break;
-                u32 m = get_move(r, e);
-                v = (m & 0xFu) ^ (m >> 4) ^ v;                   // other end of edge e
-                prev = e;
+                const u32 ec = (u32)(B >> v4) & 0xFu;
+                B ^= (u64)(ec ^ prev) << v4;             // sq[v] = prev
+                if (ec == 0u) break;                     // v was the root
+                v4 ^= __builtin_amdgcn_perm(XB1, XB0, base + ec);
+                prev = ec;
             }
         }
-        r.sq ^= (u64)(0xFu ^ n) << (x * 4u);                     // sq[x]: 0xF -> n
-        if (cyc) {
-            // board.py:44-56 + qeval.py:5-51: all squares of the component go classical, each
-            // holding its parent edge's round; x holds the closing move's round.
-            u32 s = (u32)__builtin_ctz(both);
-            u32 comp = (u32)(r.comps >> s) & 0x1FFu;
-            r.cl |= comp;
-            r.comps = comps_pop(r.comps, s);
-            if (__builtin_popcount(r.cl) == 8) {                 // board.py:22-25 autofill
-                u32 idx = (u32)__builtin_ctz(~r.cl & 0x1FFu);
-                r.sq ^= (u64)(0xFu ^ n1) << (idx * 4u);          // board[idx] = len(moves)
-                r.cl |= 1u << idx;
-                append_move(r, n1, idx | (idx << 4));
-                n1 += 1u;
-            }
-        } else if (mlo != 0u && mhi != 0u) {                     // board.py:58-61 union, pop(m1)
-            u32 s0 = (u32)__builtin_ctz(mlo), s1 = (u32)__builtin_ctz(mhi);
-            u64 c1 = (r.comps >> s1) & 0x1FFull;
-            r.comps |= c1 << s0;
-            r.comps = comps_pop(r.comps, s1);
-        } else {                                                 // board.py:62-69
-            u32 m = mlo | mhi;
-            u32 c = (u32)r.comps;
-            u32 s_new = (c & 0x1FFu) == 0u ? 0u
-                        : (c & (0x1FFu << 9)) == 0u ? 9u
-                        : (c & (0x1FFu << 18)) == 0u ? 18u : 27u;
-            u32 s = m ? (u32)__builtin_ctz(m) : s_new;
-            r.comps |= (u64)((1u << lo) | (1u << hi)) << s;
-        }
-        r.n = n1;
+        B |= (u64)(0xFu ^ n) << x4;                      // sq[x]: root -> parent edge = this move
+        B0 = (u32)B;
+        B1 = (u32)(B >> 32);
+        // board.py:19: append to the queue (the byte pushed out of A is 0 unless this is entry 9)
+        B1 |= (A1 >> 20) & 0xFF0u;
+        A1 = (A1 << 8) | (A0 >> 24);
+        A0 = (A0 << 8) | lo | (hi << 4);
+        B1 += 1u << B1_N_SHIFT;
+        // ---- board.py:42-69 on the cached qstructs, all three cases in one straight line ----
+        const u32 shi = (u32)__builtin_ctz(mhi | 0x80000000u);          // 31 when hi is in no slot
+        const u32 c1 = has_hi ? (u32)(comps >> shi) & 0x1FFu : 0u;      // component of hi
+        const bool uni = has_lo && has_hi && !cyc;                      // board.py:58-61
+        // first empty slot (slots are compact): 9 * number of non-empty slots among 0..2
+        const u32 c32 = (u32)comps;
+        const u32 nz = (((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u;
+        const u32 s_new = (u32)__builtin_popcount(nz) * 9u;
+        const u32 slo = (u32)__builtin_ctz(mlo | 0x80000000u);
+        const u32 sT = has_lo ? slo : (has_hi ? shi : s_new);           // board.py:62-69
+        comps |= (u64)(pm | (uni ? c1 : 0u)) << sT;
+        // pop hi's slot on a cycle (board.py:56) or a union (board.py:61)
+        const u32 low = ((cyc || uni) ? mhi : 0u) - 1u;                 // all ones = keep everything
+        const u32 lowh = (u32)((int)low >> 31);
+        const u64 sh9 = comps >> 9;
+        C = ((u32)comps & low) | ((u32)sh9 & ~low);
+        const u32 chi = ((u32)(comps >> 32) & lowh) | ((u32)(sh9 >> 32) & ~lowh);
+        B1 = (B1 & ~(0xFu << B1_CHI_SHIFT)) | (chi << B1_CHI_SHIFT);
+        // board.py:44-56 + qeval.py:5-51: on a cycle every square of the component goes classical
+        // and already holds its parent edge's round; x holds the closing move's round
+        B1 |= (cyc ? c1 : 0u) << B1_CL_SHIFT;
     }
-    // board.py:71-115 reduced to "does any line exist" (all env.py:49,51 need)
-    u32 odd = odd_mask(r.sq);
-    u32 w = (r.cl & ~odd) | ((r.cl & odd) << 16);
-    u32 win = any_line(w);
-    r.done = (win != 0u || r.n > 8u) ? 1u : 0u;                  // env.py:51
+    // board.py:71-115 reduced to "does any line exist" (all that env.py:49,51 need): parity of the
+    // round on each classical square -> X / O masks -> table lookup.  Nibbles are complemented, so
+    // a set low bit means an EVEN round (X).  Eight classical squares = the autofill of
+    // board.py:22-25 is due: the ninth square counts as X (round 8) and the game is over.
+    const u32 par = B0 & 0x11111111u;
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((B1 & 1u) << 8);
+    const u32 cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 pc = (u32)__builtin_popcount(cl);
+    const u32 fill = pc == 8u ? (cl ^ 0x1FFu) : 0u;
+    const u32 win = (u32)lut[(cl & even) | fill] | (u32)lut[cl & ~even];
+    // env.py:51: a line, or len(moves) > 8  <=>  at least 8 classical squares
+    B1 = (B1 & ~B1_DONE) | ((win != 0u || pc >= 8u) ? B1_DONE : 0u);
     return win;
 }
 
-// ------------------------------------------------------------------ kernels
 // BPL boards per lane: lane j owns boards [j*BPL, (j+1)*BPL), so every plane is read and written
-// with 16-byte (or 2x16-byte) vector accesses that are contiguous across the wave, and the
-// fixed per-wave cost (dispatch, address setup, waits) is paid once per BPL boards.
-#ifdef QTTT_DEBUG_STAMPS
-__device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench --stamps)
-#endif
-
-template <typename T, int N>
-struct alignas(sizeof(T) * N) Vec {
-    T v[N];
-};
-
+// with 16-byte vector accesses that are contiguous across the wave.  Addresses are a block-uniform
+// 64-bit base (scalar unit) plus a 32-bit lane offset.
 template <int BPL, bool HAS_BITS, bool AUTO_RESET>
 __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
-    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_lo,
-    u64 board_offset, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold,
+    u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
     int64_t i_begin, int64_t n_groups) {
-    int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    __shared__ uint8_t lut[512];
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (j >= n_groups) return;
-    const int64_t i0 = i_begin + j * BPL;
     typedef Vec<u64, BPL> V64;
     typedef Vec<u32, BPL> V32;
     typedef Vec<uint16_t, BPL> V16;
     typedef Vec<uint8_t, BPL> V8;
-    V64 a = *reinterpret_cast<const V64 *>(pA + i0);
-    V64 b = *reinterpret_cast<const V64 *>(pB + i0);
-    V32 c = *reinterpret_cast<const V32 *>(pC + i0);
-    V16 act = *reinterpret_cast<const V16 *>(actions + i0);
+    const int64_t jb = (int64_t)blockIdx.x * QTTT_BLOCK;          // first lane-group of the block
+    const int64_t ib = i_begin + jb * BPL;                        // first board of the block
+    const u32 left = (u32)min((int64_t)QTTT_BLOCK, n_groups - jb);
+    const bool active = threadIdx.x < left;
+    const u32 t = active ? threadIdx.x : 0u;                      // idle lanes re-read lane 0's boards
+    // issue the streaming loads first, fill the lookup table while they are in flight
+    V64 a = reinterpret_cast<const V64 *>(pA + ib)[t];
+    V64 b = reinterpret_cast<const V64 *>(pB + ib)[t];
+    V32 c = reinterpret_cast<const V32 *>(pC + ib)[t];
+    V16 act = reinterpret_cast<const V16 *>(actions + ib)[t];
     V8 bt;
-    if (HAS_BITS) bt = *reinterpret_cast<const V8 *>(bits + i0);
+    if (HAS_BITS) bt = reinterpret_cast<const V8 *>(bits + ib)[t];
+    reinterpret_cast<uint16_t *>(lut)[threadIdx.x] =
+        reinterpret_cast<const uint16_t *>(g_line_lut.b)[threadIdx.x];
+    __syncthreads();
+    if (!active) return;
     V32 rw;
     V8 tm;
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    const u32 id0 = id_base + (u32)jb * BPL + t * BPL;            // low 32 bits of the global board id
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
-        Regs r;
-        unpack(a.v[k], b.v[k], c.v[k], r);
+        u32 A0 = (u32)a.v[k], A1 = (u32)(a.v[k] >> 32);
+        u32 B0 = (u32)b.v[k], B1 = (u32)(b.v[k] >> 32);
+        u32 C = c.v[k];
         u32 bit;
         if (HAS_BITS) bit = bt.v[k] & 1u;
-        else bit = lowbias32(fold_id(board_offset + (u64)(i0 + k)) ^ key_lo) >> 31;
-        u32 av = act.v[k];
-        u32 win = step_board<AUTO_RESET>(r, av & 0xFFu, av >> 8, bit);
-        pack(r, a.v[k], b.v[k], c.v[k]);
-        rw.v[k] = win ? 0xBF800000u : 0x80000000u;               // env.py:49: -1.0f / -0.0f
-        tm.v[k] = (uint8_t)r.done;
+        else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+        const u32 win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, act.v[k], bit, lut);
+        a.v[k] = (u64)A0 | ((u64)A1 << 32);
+        b.v[k] = (u64)B0 | ((u64)B1 << 32);
+        c.v[k] = C;
+        rw.v[k] = 0x80000000u | (win << 23);                     // env.py:49: -1.0f / -0.0f
+        tm.v[k] = (uint8_t)(B1 >> 31);
     }
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st2 = __builtin_amdgcn_s_memrealtime();
 #endif
-    *reinterpret_cast<V64 *>(pA + i0) = a;
-    *reinterpret_cast<V64 *>(pB + i0) = b;
-    *reinterpret_cast<V32 *>(pC + i0) = c;
-    *reinterpret_cast<V32 *>(reward_bits + i0) = rw;
-    *reinterpret_cast<V8 *>(terminated + i0) = tm;
+    reinterpret_cast<V64 *>(pA + ib)[t] = a;
+    reinterpret_cast<V64 *>(pB + ib)[t] = b;
+    reinterpret_cast<V32 *>(pC + ib)[t] = c;
+    reinterpret_cast<V32 *>(reward_bits + ib)[t] = rw;
+    reinterpret_cast<V8 *>(terminated + ib)[t] = tm;
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st3 = __builtin_amdgcn_s_memrealtime();
@@ -300,96 +293,90 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
 #endif
 }
 
-// Persistent, software-pipelined form of step_kernel: the grid is sized to a fixed number of
-// waves per SIMD and every lane walks lane-groups j, j+stride, ...; the loads of the NEXT group
-// are issued before the current group is computed, so a wave always has memory traffic in
-// flight while its VALU work runs, and waves drift out of phase instead of all loading, then all
-// computing, then all storing (measured: DESIGN.md §6).
-template <int BPL, bool HAS_BITS>
-struct Tile {
-    Vec<u64, BPL> a, b;
-    Vec<u32, BPL> c;
-    Vec<uint16_t, BPL> act;
-    Vec<uint8_t, BPL> bt;
+// ====================================================================== cold paths
+// Friendly unpacked form for the kernels that are not on the hot path.
+struct Cold {
+    u32 n;          // n_moves
+    u32 cl;         // classical mask
+    u32 done;
+    u32 mv[9];      // mv[t] = lo | hi<<4 of round t (valid for t < n)
+    u32 sq[9];      // nibble per square
+    u32 comps[4];   // 9-bit masks, list order
 };
 
-template <int BPL, bool HAS_BITS, bool AUTO_RESET>
-__global__ __launch_bounds__(QTTT_BLOCK) void step_kernel_pipe(
-    u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
-    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_lo,
-    u64 board_offset, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
-    int64_t n_groups) {
-    const int64_t stride = (int64_t)gridDim.x * QTTT_BLOCK;
-    int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
-    if (j >= n_groups) return;
-    typedef Vec<u64, BPL> V64;
-    typedef Vec<u32, BPL> V32;
-    typedef Vec<uint16_t, BPL> V16;
-    typedef Vec<uint8_t, BPL> V8;
-    Tile<BPL, HAS_BITS> cur, nxt;
-    auto load = [&](Tile<BPL, HAS_BITS> &t, int64_t g) {
-        const int64_t i0 = g * BPL;
-        t.a = *reinterpret_cast<const V64 *>(pA + i0);
-        t.b = *reinterpret_cast<const V64 *>(pB + i0);
-        t.c = *reinterpret_cast<const V32 *>(pC + i0);
-        t.act = *reinterpret_cast<const V16 *>(actions + i0);
-        if (HAS_BITS) t.bt = *reinterpret_cast<const V8 *>(bits + i0);
-    };
-    auto process = [&](Tile<BPL, HAS_BITS> &t, int64_t g) {
-        const int64_t i0 = g * BPL;
-        V32 rw;
-        V8 tm;
-#pragma unroll
-        for (int k = 0; k < BPL; ++k) {
-            Regs r;
-            unpack(t.a.v[k], t.b.v[k], t.c.v[k], r);
-            u32 bit;
-            if (HAS_BITS) bit = t.bt.v[k] & 1u;
-            else bit = lowbias32(fold_id(board_offset + (u64)(i0 + k)) ^ key_lo) >> 31;
-            u32 av = t.act.v[k];
-            u32 win = step_board<AUTO_RESET>(r, av & 0xFFu, av >> 8, bit);
-            pack(r, t.a.v[k], t.b.v[k], t.c.v[k]);
-            rw.v[k] = win ? 0xBF800000u : 0x80000000u;
-            tm.v[k] = (uint8_t)r.done;
+__device__ inline void cold_unpack(u64 A, u64 B, u32 C, Cold &s) {
+    const u32 B1 = (u32)(B >> 32);
+    s.n = (B1 >> B1_N_SHIFT) & 0xFu;
+    s.cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
+    s.done = B1 >> 31;
+    const u32 mv8 = (B1 >> B1_MV8_SHIFT) & 0xFFu;
+    for (u32 t = 0; t < 9; ++t) {
+        u32 m = 0;
+        if (t < s.n) {
+            const u32 q = s.n - 1u - t;                          // queue index of round t
+            m = q >= 8u ? mv8 : (u32)(A >> (q * 8u)) & 0xFFu;
         }
-        *reinterpret_cast<V64 *>(pA + i0) = t.a;
-        *reinterpret_cast<V64 *>(pB + i0) = t.b;
-        *reinterpret_cast<V32 *>(pC + i0) = t.c;
-        *reinterpret_cast<V32 *>(reward_bits + i0) = rw;
-        *reinterpret_cast<V8 *>(terminated + i0) = tm;
-    };
-    // Ping-pong between two register tiles (no copies).  The first tile is peeled so that both
-    // ways into the loop header carry the same outstanding-memory-op pattern (4 loads, then the
-    // previous tile's 5 stores); otherwise the compiler's merged s_waitcnt makes every tile wait
-    // for the previous tile's stores.  Prefetches are unconditional (clamped index) for the same
-    // reason: a branch around them merges to "wait for everything".
-    int64_t j1 = j + stride;
-    bool more = j1 < n_groups;
-    load(cur, j);
-    load(nxt, more ? j1 : j);
-    process(cur, j);
-    if (!more) return;
-    for (;;) {
-        const int64_t j2 = j1 + stride;
-        const bool m2 = j2 < n_groups;
-        load(cur, m2 ? j2 : j1);
-        process(nxt, j1);
-        if (!m2) break;
-        const int64_t j3 = j2 + stride;
-        const bool m3 = j3 < n_groups;
-        load(nxt, m3 ? j3 : j2);
-        process(cur, j2);
-        if (!m3) break;
-        j1 = j3;
+        s.mv[t] = m;
+    }
+    for (u32 v = 0; v < 9; ++v) s.sq[v] = ((u32)(B >> (v * 4u)) & 0xFu) ^ 0xFu;   // stored complemented
+    const u64 comps = (u64)C | ((u64)((B1 >> B1_CHI_SHIFT) & 0xFu) << 32);
+    for (u32 k = 0; k < 4; ++k) s.comps[k] = (u32)(comps >> (9u * k)) & 0x1FFu;
+    // materialise the implicit autofill (board.py:22-25): exactly 8 classical squares
+    if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {
+        const u32 idx = (u32)__builtin_ctz(~s.cl);
+        s.sq[idx] = s.n;                                         // board[idx] = len(self.moves)
+        s.cl |= 1u << idx;
+        s.mv[s.n] = idx | (idx << 4);                            // moves.append((idx, idx, len))
+        s.n += 1u;
     }
 }
 
-__global__ __launch_bounds__(QTTT_BLOCK) void reset_kernel(u64 *pA, u64 *pB, u32 *pC, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    pA[i] = 0;
-    pB[i] = SQ_EMPTY;
-    pC[i] = 0;
+__device__ inline void cold_pack(const Cold &in, u64 &A, u64 &B, u32 &C) {
+    Cold s = in;
+    // strip an explicit autofill move (lo == hi, always the last one) back to the implicit form
+    if (s.n >= 1u && s.n <= 9u && (s.mv[s.n - 1u] & 0xFu) == (s.mv[s.n - 1u] >> 4)) {
+        const u32 idx = s.mv[s.n - 1u] & 0xFu;
+        if (idx < 9u) {
+            s.cl &= ~(1u << idx);
+            s.sq[idx] = 0xFu;
+        }
+        s.n -= 1u;
+    }
+    A = 0;
+    u32 mv8 = 0;
+    for (u32 t = 0; t < s.n && t < 9; ++t) {
+        const u32 q = s.n - 1u - t;
+        if (q >= 8u) mv8 = s.mv[t] & 0xFFu;
+        else A |= (u64)(s.mv[t] & 0xFFu) << (q * 8u);
+    }
+    u64 sq = 0;
+    for (u32 v = 0; v < 9; ++v) sq |= (u64)((s.sq[v] & 0xFu) ^ 0xFu) << (v * 4u);
+    u64 comps = 0;
+    for (u32 k = 0; k < 4; ++k) comps |= (u64)(s.comps[k] & 0x1FFu) << (9u * k);
+    const u32 B1 = (u32)(sq >> 32) | (mv8 << B1_MV8_SHIFT) | (s.n << B1_N_SHIFT) | (s.cl << B1_CL_SHIFT) |
+                   ((u32)(comps >> 32) << B1_CHI_SHIFT) | (s.done ? B1_DONE : 0u);
+    B = (u64)(u32)sq | ((u64)B1 << 32);
+    C = (u32)comps;
+}
+
+__device__ inline void cold_check_win(const Cold &s, int &p1, int &p2) {
+    // board.py:71-115, lines in the reference's order (rows, cols, 2-4-6, 0-4-8)
+    const u32 lines[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x054u, 0x111u};
+    u32 X = 0, O = 0;
+    for (u32 v = 0; v < 9; ++v)
+        if (s.cl >> v & 1u) { if (s.sq[v] & 1u) O |= 1u << v; else X |= 1u << v; }
+    p1 = 10;
+    p2 = 10;
+    for (int l = 0; l < 8; ++l) {
+        const u32 L = lines[l];
+        int mx = -1;
+        for (u32 v = 0; v < 9; ++v)
+            if (L >> v & 1u) mx = max(mx, (int)s.sq[v]);
+        if ((X & L) == L) p1 = min(p1, mx);
+        else if ((O & L) == L) p2 = min(p2, mx);
+    }
+    if (p1 >= 10) p1 = -1;
+    if (p2 >= 10) p2 = -1;
 }
 
 __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(
@@ -397,15 +384,14 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(
     uint8_t *q_p1_len, uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Regs r;
-    unpack(pA[i], pB[i], pC[i], r);
+    Cold s;
+    cold_unpack(pA[i], pB[i], pC[i], s);
     for (u32 v = 0; v < 9; ++v)                                   // env.py:71,82
-        classical[i * 9 + v] = (r.cl >> v & 1u) ? (int8_t)get_sq(r, v) : (int8_t)-1;
+        classical[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sq[v] : (int8_t)-1;
     u32 n1 = 0, n2 = 0;
     for (u32 t = 0; t < 9; ++t) {                                 // env.py:72-77
-        u32 m = get_move(r, t);
-        u32 lo = m & 0xFu, hi = m >> 4;
-        bool live = t < r.n && !(r.cl >> lo & 1u);                // round t not on the board
+        const u32 lo = s.mv[t] & 0xFu, hi = s.mv[t] >> 4;
+        const bool live = t < s.n && !(s.cl >> lo & 1u);          // round t is not on the board
         if (live && (t & 1u)) {
             q_p2[i * 8 + n2 * 2] = (uint8_t)lo;
             q_p2[i * 8 + n2 * 2 + 1] = (uint8_t)hi;
@@ -420,36 +406,17 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(
     for (u32 k = n2; k < 4; ++k) q_p2[i * 8 + k * 2] = q_p2[i * 8 + k * 2 + 1] = 255;
     q_p1_len[i] = (uint8_t)n1;
     q_p2_len[i] = (uint8_t)n2;
-    turn[i] = (uint8_t)(r.n & 1u);                                // env.py:83
-}
-
-__device__ inline void check_win_regs(const Regs &r, int &p1, int &p2) {
-    // board.py:71-115, lines in the reference's order (rows, cols, 2-4-6, 0-4-8)
-    const u32 lines[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x054u, 0x111u};
-    u32 odd = odd_mask(r.sq);
-    u32 X = r.cl & ~odd, O = r.cl & odd;
-    p1 = 10;
-    p2 = 10;
-    for (int l = 0; l < 8; ++l) {
-        u32 L = lines[l];
-        int mx = -1;
-        for (u32 v = 0; v < 9; ++v)
-            if (L >> v & 1u) mx = max(mx, (int)get_sq(r, v));
-        if ((X & L) == L) p1 = min(p1, mx);
-        else if ((O & L) == L) p2 = min(p2, mx);
-    }
-    if (p1 >= 10) p1 = -1;
-    if (p2 >= 10) p2 = -1;
+    turn[i] = (uint8_t)(s.n & 1u);                                // env.py:83
 }
 
 __global__ __launch_bounds__(QTTT_BLOCK) void check_win_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, int8_t *p1_round, int8_t *p2_round, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Regs r;
-    unpack(pA[i], pB[i], pC[i], r);
+    Cold s;
+    cold_unpack(pA[i], pB[i], pC[i], s);
     int p1, p2;
-    check_win_regs(r, p1, p2);
+    cold_check_win(s, p1, p2);
     p1_round[i] = (int8_t)p1;
     p2_round[i] = (int8_t)p2;
 }
@@ -459,22 +426,20 @@ __global__ __launch_bounds__(QTTT_BLOCK) void export_kernel(
     int8_t *board, uint16_t *qmask, uint8_t *n_q, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Regs r;
-    unpack(pA[i], pB[i], pC[i], r);
+    Cold s;
+    cold_unpack(pA[i], pB[i], pC[i], s);
     for (u32 t = 0; t < 9; ++t) {
-        u32 m = get_move(r, t);
-        bool used = t < r.n;
-        moves[i * 18 + t * 2] = used ? (uint8_t)(m & 0xFu) : (uint8_t)255;
-        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)(m >> 4) : (uint8_t)255;
+        const bool used = t < s.n;
+        moves[i * 18 + t * 2] = used ? (uint8_t)(s.mv[t] & 0xFu) : (uint8_t)255;
+        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)(s.mv[t] >> 4) : (uint8_t)255;
     }
-    n_moves[i] = (uint8_t)r.n;
+    n_moves[i] = (uint8_t)s.n;
     for (u32 v = 0; v < 9; ++v)
-        board[i * 9 + v] = (r.cl >> v & 1u) ? (int8_t)get_sq(r, v) : (int8_t)-1;
+        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sq[v] : (int8_t)-1;
     u32 nq = 0;
     for (u32 k = 0; k < 4; ++k) {
-        u32 c = (u32)(r.comps >> (9u * k)) & 0x1FFu;
-        qmask[i * 4 + k] = (uint16_t)c;
-        nq += c != 0u;
+        qmask[i * 4 + k] = (uint16_t)s.comps[k];
+        nq += s.comps[k] != 0u;
     }
     n_q[i] = (uint8_t)nq;
 }
@@ -486,53 +451,46 @@ __global__ __launch_bounds__(QTTT_BLOCK) void import_kernel(
     const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Regs r;
-    regs_reset(r);
-    u32 nm = min((u32)n_moves[i], 9u);
-    r.n = nm;
-    for (u32 t = 0; t < nm; ++t)
-        append_move(r, t, (u32)(moves[i * 18 + t * 2] & 0xFu) | ((u32)(moves[i * 18 + t * 2 + 1] & 0xFu) << 4));
+    Cold s;
+    s.n = min((u32)n_moves[i], 9u);
+    s.cl = 0;
+    for (u32 t = 0; t < 9; ++t)
+        s.mv[t] = t < s.n ? ((u32)(moves[i * 18 + t * 2] & 0xFu) | ((u32)(moves[i * 18 + t * 2 + 1] & 0xFu) << 4)) : 0u;
     for (u32 v = 0; v < 9; ++v) {
-        int bv = board[i * 9 + v];
+        const int bv = board[i * 9 + v];
+        s.sq[v] = 0xFu;
         if (bv >= 0) {
-            r.cl |= 1u << v;
-            r.sq ^= (u64)(0xFu ^ ((u32)bv & 0xFu)) << (v * 4u);
+            s.cl |= 1u << v;
+            s.sq[v] = (u32)bv & 0xFu;
         }
     }
-    u32 nq = min((u32)n_q[i], 4u);
-    for (u32 k = 0; k < nq; ++k) r.comps |= (u64)(qmask[i * 4 + k] & 0x1FFu) << (9u * k);
+    const u32 nq = min((u32)n_q[i], 4u);
+    for (u32 k = 0; k < 4; ++k) s.comps[k] = k < nq ? (qmask[i * 4 + k] & 0x1FFu) : 0u;
     // root every tree of live edges: grow from the lowest square of each tree
     u32 rooted = 0;
     for (int pass = 0; pass < 9; ++pass) {
         bool grew = false;
-        for (u32 t = 0; t < nm; ++t) {
-            u32 m = get_move(r, t);
-            u32 lo = m & 0xFu, hi = m >> 4;
-            if (lo == hi || lo > 8u || hi > 8u || (r.cl >> lo & 1u) || (r.cl >> hi & 1u)) continue;
-            bool rl = rooted >> lo & 1u, rh = rooted >> hi & 1u;
-            if (rl && !rh) { r.sq ^= (u64)(get_sq(r, hi) ^ t) << (hi * 4u); rooted |= 1u << hi; grew = true; }
-            else if (rh && !rl) { r.sq ^= (u64)(get_sq(r, lo) ^ t) << (lo * 4u); rooted |= 1u << lo; grew = true; }
+        u32 cand = 0;
+        for (u32 t = 0; t < s.n; ++t) {
+            const u32 lo = s.mv[t] & 0xFu, hi = s.mv[t] >> 4;
+            if (lo == hi || lo > 8u || hi > 8u || (s.cl >> lo & 1u) || (s.cl >> hi & 1u)) continue;
+            const bool rl = rooted >> lo & 1u, rh = rooted >> hi & 1u;
+            if (rl && !rh) { s.sq[hi] = t; rooted |= 1u << hi; grew = true; }
+            else if (rh && !rl) { s.sq[lo] = t; rooted |= 1u << lo; grew = true; }
+            cand |= (1u << lo) | (1u << hi);
         }
         if (!grew) {
-            // start a new tree at the lowest un-rooted square that has a live edge
-            u32 cand = 0;
-            for (u32 t = 0; t < nm; ++t) {
-                u32 m = get_move(r, t);
-                u32 lo = m & 0xFu, hi = m >> 4;
-                if (lo == hi || lo > 8u || hi > 8u || (r.cl >> lo & 1u) || (r.cl >> hi & 1u)) continue;
-                cand |= (1u << lo) | (1u << hi);
-            }
-            cand &= ~rooted;
+            cand &= ~rooted;                 // start a new tree at the lowest un-rooted square
             if (cand == 0u) break;
             rooted |= cand & (0u - cand);
         }
     }
     int p1, p2;
-    check_win_regs(r, p1, p2);
-    r.done = (p1 > 0 || p2 > 0 || r.n > 8u) ? 1u : 0u;
+    cold_check_win(s, p1, p2);
+    s.done = (p1 > 0 || p2 > 0 || s.n > 8u) ? 1u : 0u;
     u64 A, B;
     u32 C;
-    pack(r, A, B, C);
+    cold_pack(s, A, B, C);
     pA[i] = A;
     pB[i] = B;
     pC[i] = C;
@@ -540,31 +498,30 @@ __global__ __launch_bounds__(QTTT_BLOCK) void import_kernel(
 
 // legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
 __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, u32 key_lo, u32 key_hi, u64 board_offset,
-    u32 auto_reset, uint8_t *actions, int64_t n) {
+    const u64 *pB, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint8_t *actions,
+    int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Regs r;
-    unpack(pA[i], pB[i], pC[i], r);
-    u32 cl = (auto_reset && r.done) ? 0u : r.cl;
-    u32 empty = ~cl & 0x1FFu;
-    u32 e = (u32)__builtin_popcount(empty);
-    u32 n_legal = e * (e - 1u) / 2u;
+    const u32 B1 = (u32)(pB[i] >> 32);
+    const u32 cl = (auto_reset && (B1 >> 31)) ? 0u : (B1 >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 empty = ~cl & 0x1FFu;
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 n_legal = e * (e - 1u) / 2u;
     u32 lo = 0, hi = 0;
     if (n_legal != 0u) {
-        u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
-        u32 h2 = lowbias32(h1 ^ key_hi);
+        const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
+        const u32 h2 = lowbias32(h1 ^ key_hi);
         u32 k = __umulhi(h2, n_legal);
-        // walk the empty squares: the j-th empty square (ascending) pairs with the e-1-j later ones
+        // the j-th empty square (ascending) pairs with the e-1-j later ones
         u32 rest = empty, left = e;
         for (int it = 0; it < 9; ++it) {
-            u32 v = (u32)__builtin_ctz(rest);
+            const u32 v = (u32)__builtin_ctz(rest);
             rest &= rest - 1u;
             left -= 1u;
             if (k < left) {
                 lo = v;
                 u32 rr = rest;
-                for (u32 j = 0; j < k; ++j) rr &= rr - 1u;
+                for (u32 jj = 0; jj < k; ++jj) rr &= rr - 1u;
                 hi = (u32)__builtin_ctz(rr);
                 break;
             }
@@ -575,24 +532,16 @@ __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     actions[i * 2 + 1] = (uint8_t)hi;
 }
 
-// tuning knobs (bench / profiling): boards per lane (1|2|4) and, for the persistent pipelined
-// form, waves per SIMD (0 = plain one-shot grid).  Initialised from QTTT_STEP_BPL /
-// QTTT_STEP_PIPE, changeable at run time through qttt_set_tuning().
-struct Tuning {
-    int bpl;
-    int pipe;
-};
-inline Tuning &tuning() {
-    static Tuning t = [] {
-        Tuning v{QTTT_DEFAULT_BPL, QTTT_DEFAULT_PIPE};
-        if (const char *e = getenv("QTTT_STEP_BPL")) { int k = atoi(e); if (k == 1 || k == 2 || k == 4) v.bpl = k; }
-        if (const char *e = getenv("QTTT_STEP_PIPE")) { int k = atoi(e); if (k >= 0 && k <= 8) v.pipe = k; }
-        return v;
+// tuning knob (bench / profiling): boards per lane of the step kernel (1|2|4).  Initialised from
+// QTTT_STEP_BPL, changeable at run time through qttt_set_tuning().
+inline int &tuning_bpl() {
+    static int v = [] {
+        int k = QTTT_DEFAULT_BPL;
+        if (const char *e = getenv("QTTT_STEP_BPL")) { int q = atoi(e); if (q == 1 || q == 2 || q == 4) k = q; }
+        return k;
     }();
-    return t;
+    return v;
 }
-inline int step_bpl_override() { return tuning().bpl; }
-inline int step_pipe_override() { return tuning().pipe; }
 
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
 
@@ -615,34 +564,29 @@ int qttt_debug_set_stamps(void *buf) {
 }
 #endif
 
-int qttt_set_tuning(int boards_per_lane, int pipe_waves_per_simd) {
+int qttt_set_tuning(int boards_per_lane, int reserved) {
+    (void)reserved;
     if (!(boards_per_lane == 1 || boards_per_lane == 2 || boards_per_lane == 4)) return QTTT_ERR_SIZE;
-    if (pipe_waves_per_simd < 0 || pipe_waves_per_simd > 8) return QTTT_ERR_SIZE;
-    tuning().bpl = boards_per_lane;
-    tuning().pipe = pipe_waves_per_simd;
+    tuning_bpl() = boards_per_lane;
     return 0;
 }
 
 int64_t qttt_state_bytes(int64_t n) { return n < 0 ? (int64_t)QTTT_ERR_SIZE : plane_stride(n) * 20; }
 
 uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx) {
-    u64 key = launch_key(seed, step_idx);
-    u32 x = fold_id(board_id) ^ (u32)key;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    u32 h1 = x;
-    x = h1 ^ (u32)(key >> 32);
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return ((u64)x << 32) | h1;
+    const u64 key = launch_key(seed, step_idx);
+    const u32 h1 = lowbias32(fold_id(board_id) ^ (u32)key);
+    const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+    return ((u64)h2 << 32) | h1;
 }
 
 int qttt_reset(void *state, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state) return QTTT_ERR_NULL;
-    Planes p = planes(state, n);
-    hipLaunchKernelGGL(reset_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, n);
-    return launch_status();
+    // the empty board is the all-zero state
+    hipError_t e = hipMemsetAsync(state, 0, (size_t)(plane_stride(n) * 20), (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
@@ -653,52 +597,49 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
     if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are read as u16 pairs
     Planes p = planes(state, n);
-    u32 key_lo = (u32)launch_key(seed, step_idx);
+    const u32 key_lo = (u32)launch_key(seed, step_idx);
     hipStream_t s = (hipStream_t)stream;
     const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
     u32 *rb = reinterpret_cast<u32 *>(reward);
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
-    // widest boards-per-lane the caller's pointers are aligned for (planes always are)
-    int bpl = step_bpl_override();
+    // widest boards-per-lane the caller's pointers are aligned for (the planes always are)
+    int bpl_max = tuning_bpl();
     auto aligned = [&](int k) {
         return ((uintptr_t)actions % (2u * k)) == 0 && ((uintptr_t)reward % (4u * k)) == 0 &&
                ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
     };
-    while (bpl > 1 && !aligned(bpl)) bpl >>= 1;
-    const int64_t n_groups = n / bpl, n_main = n_groups * bpl;
-#define QTTT_LAUNCH(BPL, HB, AR, I0, NG)                                                        \
+    while (bpl_max > 1 && !aligned(bpl_max)) bpl_max >>= 1;
+#define QTTT_LAUNCH(BPL, HB, AR, I0, NG, KF, IDB)                                               \
     hipLaunchKernelGGL((step_kernel<BPL, HB, AR>), dim3(grid_for(NG)), dim3(QTTT_BLOCK), 0, s,  \
-                       p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated,     \
+                       p.A, p.B, p.C, a16, bits, (u32)(KF), (u32)(IDB), rb, terminated,         \
                        (int64_t)(I0), (int64_t)(NG))
-#define QTTT_DISPATCH(BPL, I0, NG)                                   \
+#define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                          \
     do {                                                             \
-        if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, I0, NG); else QTTT_LAUNCH(BPL, true, false, I0, NG); } \
-        else      { if (ar) QTTT_LAUNCH(BPL, false, true, I0, NG); else QTTT_LAUNCH(BPL, false, false, I0, NG); } \
+        if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, I0, NG, KF, IDB); } \
+        else      { if (ar) QTTT_LAUNCH(BPL, false, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, I0, NG, KF, IDB); } \
     } while (0)
-    const int pipe = step_pipe_override();      // waves per SIMD of the persistent form, 0 = off
-    if (n_groups > 0 && pipe > 0) {
-        int64_t blocks = (n_groups + QTTT_BLOCK - 1) / QTTT_BLOCK;
-        const int64_t cap = (int64_t)256 * pipe;  // 256 CUs x (pipe waves/SIMD x 4 SIMDs / 4 waves per block)
-        if (blocks > cap) blocks = cap;
-#define QTTT_LAUNCH_P(BPL, HB, AR)                                                               \
-    hipLaunchKernelGGL((step_kernel_pipe<BPL, HB, AR>), dim3((unsigned)blocks), dim3(QTTT_BLOCK), 0, s, \
-                       p.A, p.B, p.C, a16, bits, key_lo, (u64)board_offset, rb, terminated, n_groups)
-#define QTTT_DISPATCH_P(BPL)                                          \
-    do {                                                              \
-        if (bits) { if (ar) QTTT_LAUNCH_P(BPL, true, true); else QTTT_LAUNCH_P(BPL, true, false); } \
-        else      { if (ar) QTTT_LAUNCH_P(BPL, false, true); else QTTT_LAUNCH_P(BPL, false, false); } \
-    } while (0)
-        if (bpl == 4) QTTT_DISPATCH_P(4);
-        else if (bpl == 2) QTTT_DISPATCH_P(2);
-        else QTTT_DISPATCH_P(1);
-#undef QTTT_DISPATCH_P
-#undef QTTT_LAUNCH_P
-    } else if (n_groups > 0) {
-        if (bpl == 4) QTTT_DISPATCH(4, 0, n_groups);
-        else if (bpl == 2) QTTT_DISPATCH(2, 0, n_groups);
-        else QTTT_DISPATCH(1, 0, n_groups);
+    // The hash folds the global board id as lo32 ^ hi32*C (fold_id).  hi32 is uniform over a
+    // range of boards unless the range crosses a multiple of 2^32; the batch is cut there (at most
+    // once), so the kernel only ever adds a lane index to a 32-bit base.
+    int64_t seg_begin = 0;
+    while (seg_begin < n) {
+        const u64 first = (u64)board_offset + (u64)seg_begin;
+        const u64 to_boundary = (((first >> 32) + 1u) << 32) - first;
+        const int64_t seg_n = (int64_t)((u64)(n - seg_begin) < to_boundary ? (u64)(n - seg_begin) : to_boundary);
+        const u32 key_fold = key_lo ^ ((u32)(first >> 32) * 0x9E3779B9u);
+        const u32 id_base = (u32)first;
+        int bpl = bpl_max;
+        while (bpl > 1 && (seg_begin % bpl) != 0) bpl >>= 1;     // vector accesses need an aligned start
+        const int64_t n_groups = seg_n / bpl, n_main = n_groups * bpl;
+        if (n_groups > 0) {
+            if (bpl == 4) QTTT_DISPATCH(4, seg_begin, n_groups, key_fold, id_base);
+            else if (bpl == 2) QTTT_DISPATCH(2, seg_begin, n_groups, key_fold, id_base);
+            else QTTT_DISPATCH(1, seg_begin, n_groups, key_fold, id_base);
+        }
+        if (n_main < seg_n)                                      // ragged tail, one board per lane
+            QTTT_DISPATCH(1, seg_begin + n_main, seg_n - n_main, key_fold, id_base + (u32)n_main);
+        seg_begin += seg_n;
     }
-    if (n_main < n) QTTT_DISPATCH(1, n_main, n - n_main);        // ragged tail, one board per lane
 #undef QTTT_DISPATCH
 #undef QTTT_LAUNCH
     return launch_status();
@@ -768,10 +709,10 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int
     if (n == 0) return 0;
     if (!state || !actions) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    u64 key = launch_key(seed, step_idx);
+    const u64 key = launch_key(seed, step_idx);
     hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0,
-                       (hipStream_t)stream, p.A, p.B, p.C, (u32)key, (u32)(key >> 32),
-                       (u64)board_offset, (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), actions, n);
+                       (hipStream_t)stream, p.B, (u32)key, (u32)(key >> 32), (u64)board_offset,
+                       (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), actions, n);
     return launch_status();
 }
 

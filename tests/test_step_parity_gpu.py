@@ -161,6 +161,24 @@ def test_shard_equals_slice_of_single_run():
             assert torch.equal(es[key], ef[key][sl]), key
 
 
+def test_board_ids_across_the_2_pow_32_boundary():
+    """The hash folds the 64-bit global board id; a batch whose ids cross a multiple of 2^32 is
+    cut there inside qttt_step (ragged cut: 1001 boards before the boundary)."""
+    from qtttgym_amd import VecEnv
+    n, off, seed = 4096, (1 << 32) - 1001, 5
+    env = VecEnv(n, seed=seed, auto_reset=True, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    for t in range(12):
+        a = env.sample_actions()
+        a_or = ob.sample_actions(seed, t, off, True)
+        assert np.array_equal(_np(a), a_or), t
+        reward, term = env.step_raw(a)
+        r_or, t_or = ob.step(a_or, None, seed, t, off, True)
+        assert np.array_equal(_np(reward).view(np.uint32), r_or.view(np.uint32)), t
+        assert np.array_equal(_np(term).astype(np.uint8), t_or), t
+    assert_same_as_oracle(env, ob)
+
+
 def test_empty_batch_and_argument_errors():
     from qtttgym_amd import VecEnv, _native
     env = VecEnv(0)
