@@ -40,7 +40,9 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+#ifndef QTTT_BLOCK
 #define QTTT_BLOCK 256
+#endif
 #define QTTT_DEFAULT_BPL 2
 
 namespace {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold,
     u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
     int64_t i_begin, int64_t n_groups) {
-    __shared__ uint8_t lut[512];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     V16 act = reinterpret_cast<const V16 *>(actions + ib)[t];
     V8 bt;
     if (HAS_BITS) bt = reinterpret_cast<const V8 *>(bits + ib)[t];
-    reinterpret_cast<uint16_t *>(lut)[threadIdx.x] =
-        reinterpret_cast<const uint16_t *>(g_line_lut.b)[threadIdx.x];
+    for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
+        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
     __syncthreads();
     if (!active) return;
     V32 rw;
@@ -281,8 +283,13 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     reinterpret_cast<V64 *>(pA + ib)[t] = a;
     reinterpret_cast<V64 *>(pB + ib)[t] = b;
     reinterpret_cast<V32 *>(pC + ib)[t] = c;
+#ifdef QTTT_NT_STORES
+    __builtin_nontemporal_store(rw, &reinterpret_cast<V32 *>(reward_bits + ib)[t]);
+    __builtin_nontemporal_store(tm, &reinterpret_cast<V8 *>(terminated + ib)[t]);
+#else
     reinterpret_cast<V32 *>(reward_bits + ib)[t] = rw;
     reinterpret_cast<V8 *>(terminated + ib)[t] = tm;
+#endif
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st3 = __builtin_amdgcn_s_memrealtime();
