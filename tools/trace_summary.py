@@ -17,7 +17,7 @@ def main():
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"]]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-    name = rows[0]["Kernel_Name"].split("(")[0]
+    import re; name = re.search(r"step_kernel<[^>]*>", rows[0]["Kernel_Name"]).group(0)
     print("kernel: %s" % name)
     print("VGPR_Count=%s SGPR_Count=%s Workgroup_Size=%s Grid_Size=%s" % (
         rows[-1].get("VGPR_Count"), rows[-1].get("SGPR_Count"), rows[-1].get("Workgroup_Size"),
