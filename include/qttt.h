@@ -94,6 +94,41 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx,
                         int64_t board_offset, uint32_t flags, uint8_t *actions, int64_t n,
                         void *stream);
 
+/* ---- next rows: the callers either side of the path -------------------------- */
+
+/* What an MCTS node needs about a state (GameState, mcts.py:9-94):
+ *   winner i8[n]   1 = True (p1), 0 = False (p2), -1 = None   (update_winner, mcts.py:52-65)
+ *   terminal u8[n] line or len(moves) == 9                     (mcts.py:65)
+ *   legal u64[n]   bit a = action a in GameState.actions       (mcts.py:20-27, ind2move order)
+ *   key i64[n]     GameState.__hash__ (mcts.py:93-94) = CPython (>= 3.8) hash(tuple(board) +
+ *                  tuple(moves)), bit-exact, so keys match a host-side transposition table */
+int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                   int64_t *key, int64_t n, void *stream);
+
+/* MCTS._step (mcts.py:233-267) for n (state, action) pairs, both collapse branches at once.
+ *   action36 u8[n]    index into ind2move order (mcts.py:339-343); > 35 is illegal
+ *   child0, child1    packed states, qttt_state_bytes(n) each (child 1 meaningful when n_children == 2)
+ *   n_children u8[n]  0 = make_move raises (children = copies of the parent), 1 = no collapse,
+ *                     2 = collapse: child 0 = closing move on min(a,b) (bit 0), child 1 = on max(a,b)
+ *   winner i8[n,2], terminal u8[n,2], legal u64[n,2], key i64[n,2]: as qttt_node_info, per child
+ * The reference returns the two children in random order; compare as a set. */
+int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *child1,
+                uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                int64_t *key, int64_t n, void *stream);
+
+/* MCTS._simulate (mcts.py:185-198) with the uniform priors of mcts.py:287-292: uniform-legal random
+ * playout to the end with the board in registers; ply p draws action and collapse branch from the
+ * counter hash of (seed, board_offset+i, step_idx0+p), i.e. exactly what qttt_sample_actions +
+ * qttt_step would do launch by launch.
+ *   result i8[n]   MCTS._reward (mcts.py:200-209): +1 winner True, -1 winner False, 0 None
+ *   plies u8[n]    moves played; final_state (nullable): packed end states */
+int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
+                 int8_t *result, uint8_t *plies, void *final_state, int64_t n, void *stream);
+
+/* GameState.to_vector (mcts.py:67-85) -> vec f32[n,18,10]; action_mask (mcts.py:87-91) ->
+ * mask u8[n,36] (nullable).  The reference builds float64; values are 0, 1 and 1/3 rounded to f32. */
+int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *stream);
+
 /* Launch-shape knob of qttt_step (results never depend on it): boards per lane (1, 2 or 4).
  * Process-wide; also settable through QTTT_STEP_BPL before the first call.  `reserved` = 0. */
 int qttt_set_tuning(int boards_per_lane, int reserved);

@@ -72,6 +72,8 @@ def lib():
         L.qo_legal_mask.argtypes = [vp]
         L.qo_legal_mask.restype = u64
         L.qo_to_vector.argtypes = [vp, vp]
+        L.qo_pyhash.argtypes = [vp]
+        L.qo_pyhash.restype = i64
         _lib = L
     return _lib
 
@@ -175,6 +177,99 @@ class OracleBoards:
         L = lib()
         base = self.b.ctypes.data
         return np.array([L.qo_terminated(base + 48 * i) for i in range(self.n)], dtype=np.uint8)
+
+
+def boards_from_arrays(board, moves, n_moves, qmask, n_q):
+    """OracleBoards from reference-shaped arrays (the golden / export conventions)."""
+    n = len(n_moves)
+    ob = OracleBoards(n)
+    ob.b["board"] = np.asarray(board, dtype=np.int8)
+    mv = np.asarray(moves).astype(np.int16)
+    mv[mv == 255] = -1
+    ob.b["moves"] = mv.astype(np.int8)
+    ob.b["n_moves"] = np.asarray(n_moves, dtype=np.int32)
+    ob.b["q"][:, :4] = np.asarray(qmask, dtype=np.uint16)
+    ob.b["n_q"] = np.asarray(n_q, dtype=np.int32)
+    return ob
+
+
+def expand(ob, action36):
+    """qo_expand over a batch -> (n_children, child OracleBoards x2, winner[n,2], terminal[n,2],
+    legal u64[n,2], key i64[n,2])."""
+    n = ob.n
+    kids = [OracleBoards(n), OracleBoards(n)]
+    nch = np.zeros(n, dtype=np.uint8)
+    winner = np.full((n, 2), -1, dtype=np.int8)
+    terminal = np.zeros((n, 2), dtype=np.uint8)
+    legal = np.zeros((n, 2), dtype=np.uint64)
+    key = np.zeros((n, 2), dtype=np.int64)
+    L = lib()
+    child = np.zeros(2, dtype=BOARD_DTYPE)
+    w = (ctypes.c_int * 2)()
+    t = (ctypes.c_int * 2)()
+    lm = (ctypes.c_uint64 * 2)()
+    base = ob.b.ctypes.data
+    for i in range(n):
+        k = L.qo_expand(base + 48 * i, int(action36[i]), _ptr(child), w, t, lm)
+        nch[i] = k
+        for c in range(k):
+            kids[c].b[i] = child[c]
+            winner[i, c], terminal[i, c], legal[i, c] = w[c], t[c], lm[c]
+            key[i, c] = L.qo_pyhash(child[c:c + 1].ctypes.data)
+        for c in range(k, 2):
+            kids[c].b[i] = ob.b[i]
+    return nch, kids, winner, terminal, legal, key
+
+
+def node_info(ob):
+    n = ob.n
+    winner = np.empty(n, dtype=np.int8)
+    terminal = np.empty(n, dtype=np.uint8)
+    legal = np.empty(n, dtype=np.uint64)
+    key = np.empty(n, dtype=np.int64)
+    L = lib()
+    w, t = ctypes.c_int(), ctypes.c_int()
+    base = ob.b.ctypes.data
+    for i in range(n):
+        L.qo_update_winner(base + 48 * i, ctypes.byref(w), ctypes.byref(t))
+        winner[i], terminal[i] = w.value, t.value
+        legal[i] = L.qo_legal_mask(base + 48 * i)
+        key[i] = L.qo_pyhash(base + 48 * i)
+    return winner, terminal, legal, key
+
+
+def to_vector(ob):
+    out = np.empty((ob.n, 18, 10), dtype=np.float64)
+    L = lib()
+    base = ob.b.ctypes.data
+    for i in range(ob.n):
+        L.qo_to_vector(base + 48 * i, out[i].ctypes.data)
+    return out
+
+
+def rollout(ob, seed, step_idx0, board_offset=0):
+    """MCTS._simulate under uniform priors, restated as the sample/step loop it is: ply p uses
+    the hash of (seed, id, step_idx0+p).  Returns (result i8[n] per MCTS._reward, plies u8[n],
+    final OracleBoards)."""
+    n = ob.n
+    cur = ob.copy()
+    plies = np.zeros(n, dtype=np.uint8)
+    L = lib()
+    for i in range(n):
+        p = cur.b[i:i + 1]
+        ptr = p.ctypes.data
+        act = np.zeros(2, dtype=np.uint8)
+        r, tm, cons = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+        k = 0
+        while k < 9 and not L.qo_terminated(ptr) and bin(int(L.qo_legal_mask(ptr))).count("1") > 0:
+            L.qo_sample_action(ptr, int(seed), int(board_offset + i), int(step_idx0 + k), _ptr(act))
+            bit = L.qo_collapse_bit(int(seed), int(board_offset + i), int(step_idx0 + k))
+            L.qo_step(ptr, int(act[0]), int(act[1]), bit, ctypes.byref(r), ctypes.byref(tm), ctypes.byref(cons))
+            k += 1
+        plies[i] = k
+    winner, _, _, _ = node_info(cur)
+    result = np.where(winner < 0, 0, np.where(winner > 0, 1, -1)).astype(np.int8)
+    return result, plies, cur
 
 
 def collapse_bit(seed, board_id, step_idx):

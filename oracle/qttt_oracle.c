@@ -345,3 +345,32 @@ void qo_to_vector(const qo_board *b, double out[180]) {   /* mcts.py:67-85 */
     for (int s = 0; s < 9; ++s)                           /* :81-84 */
         if (!(qsets >> s & 1)) out[(9 + s) * 10 + 9] = 1.0;
 }
+
+/* ------------------------------------------------------------------ mcts.py:93-94
+ * GameState.__hash__ = hash(tuple(self.board) + tuple(self.moves)).  The arithmetic is CPython's
+ * (third party to the reference): Objects/tupleobject.c `tuplehash` (xxHash-style, CPython >= 3.8,
+ * pinned here to the 3.10.12 of this image) and Objects/longobject.c `long_hash` (small ints hash
+ * to themselves, -1 hashes to -2).  Checked against the running interpreter's hash() in
+ * tests/test_next_rows_cpu.py and against the hashes recorded from the reference. */
+static uint64_t py_acc(uint64_t acc, uint64_t lane) {
+    acc += lane * 14029467366897019727ull;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * 11400714785074694791ull;
+}
+static uint64_t py_fin(uint64_t acc, uint64_t len) {
+    acc += len ^ (2870177450012600261ull ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+int64_t qo_pyhash(const qo_board *b) {
+    uint64_t acc = 2870177450012600261ull;
+    for (int i = 0; i < 9; ++i)
+        acc = py_acc(acc, b->board[i] == -1 ? (uint64_t)(int64_t)-2 : (uint64_t)b->board[i]);
+    for (int t = 0; t < b->n_moves; ++t) {
+        uint64_t in = 2870177450012600261ull;
+        in = py_acc(in, (uint64_t)b->moves[t][0]);
+        in = py_acc(in, (uint64_t)b->moves[t][1]);
+        in = py_acc(in, (uint64_t)t);
+        acc = py_acc(acc, py_fin(in, 3));
+    }
+    return (int64_t)py_fin(acc, (uint64_t)(9 + b->n_moves));
+}

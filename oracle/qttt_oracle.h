@@ -68,6 +68,8 @@ void qo_update_winner(const qo_board *b, int *winner, int *terminal); /* mcts.py
 uint64_t qo_legal_mask(const qo_board *b);                         /* mcts.py:20-27  */
 /* mcts.py:67-85 to_vector: out[18][10] row-major, f64 like numpy's default. */
 void qo_to_vector(const qo_board *b, double out[180]);
+/* mcts.py:93-94 under CPython >= 3.8 */
+int64_t qo_pyhash(const qo_board *b);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,10 @@ SIGNATURES = {
     "qttt_export": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_import": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
+    "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_expand": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_rollout": (_i32, [_vp, _u64, _u32, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_encode": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_set_tuning": (_i32, [_i32, _i32]),
     "qttt_hash": (_u64, [_u64, _u64, _u32]),
 }

@@ -539,6 +539,215 @@ __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     actions[i * 2 + 1] = (uint8_t)hi;
 }
 
+// ====================================================================== §8(f) rows
+// ind2move (mcts.py:339-343): lexicographic pairs (0,1),(0,2)..(7,8) as lo | hi<<4
+struct PairLut {
+    uint8_t b[36];
+    constexpr PairLut() : b() {
+        int a = 0;
+        for (int i = 0; i < 9; ++i)
+            for (int j = i + 1; j < 9; ++j) b[a++] = (uint8_t)(i | (j << 4));
+    }
+};
+__constant__ PairLut g_pair_lut = PairLut();
+
+__device__ inline void fill_line_lut(uint8_t *lut) {
+    for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
+        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
+    __syncthreads();
+}
+
+// GameState.actions (mcts.py:20-27): action a is listed iff both its squares are classical-empty
+__device__ inline u64 cold_legal_mask(const Cold &s) {
+    u64 m = 0;
+    for (int a = 0; a < 36; ++a) {
+        const u32 pr = g_pair_lut.b[a];
+        if (!((s.cl >> (pr & 0xFu)) & 1u) && !((s.cl >> (pr >> 4)) & 1u)) m |= 1ull << a;
+    }
+    return m;
+}
+
+// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal
+__device__ inline void cold_update_winner(const Cold &s, int &winner, int &terminal) {
+    int p1, p2;
+    cold_check_win(s, p1, p2);
+    winner = -1;
+    terminal = 0;
+    if (p1 > 0 && p2 > 0) { winner = p1 < p2; terminal = 1; }
+    else if (p2 < 0 && p1 > 0) { winner = 1; terminal = 1; }
+    else if (p1 < 0 && p2 > 0) { winner = 0; terminal = 1; }
+    terminal = (s.n == 9u) || terminal;
+}
+
+// GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
+// (Objects/tupleobject.c tuplehash, xxHash-style; hash(int) = the int, hash(-1) = -2).
+__device__ inline u64 py_tuple_acc(u64 acc, u64 lane) {
+    acc += lane * 14029467366897019727ull;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * 11400714785074694791ull;
+}
+__device__ inline u64 py_tuple_fin(u64 acc, u64 len) {
+    acc += len ^ (2870177450012600261ull ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+__device__ inline int64_t cold_py_hash(const Cold &s) {
+    u64 acc = 2870177450012600261ull;
+    for (u32 v = 0; v < 9; ++v)
+        acc = py_tuple_acc(acc, (s.cl >> v & 1u) ? (u64)s.sq[v] : (u64)(int64_t)-2);
+    for (u32 t = 0; t < s.n; ++t) {
+        u64 in = 2870177450012600261ull;
+        in = py_tuple_acc(in, (u64)(s.mv[t] & 0xFu));
+        in = py_tuple_acc(in, (u64)(s.mv[t] >> 4));
+        in = py_tuple_acc(in, (u64)t);
+        acc = py_tuple_acc(acc, py_tuple_fin(in, 3));
+    }
+    return (int64_t)py_tuple_fin(acc, 9u + s.n);
+}
+
+__global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
+    const u64 *pA, const u64 *pB, const u32 *pC, int8_t *winner, uint8_t *terminal, u64 *legal,
+    int64_t *key, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_unpack(pA[i], pB[i], pC[i], s);
+    int w, t;
+    cold_update_winner(s, w, t);
+    winner[i] = (int8_t)w;
+    terminal[i] = (uint8_t)t;
+    legal[i] = cold_legal_mask(s);
+    key[i] = cold_py_hash(s);
+}
+
+// MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
+// re-sampling make_move until the other branch appears.
+__global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
+    const u64 *pA, const u64 *pB, const u32 *pC, const uint8_t *action36,
+    u64 *c0A, u64 *c0B, u32 *c0C, u64 *c1A, u64 *c1B, u32 *c1C, uint8_t *n_children,
+    int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
+    fill_line_lut(lut);
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 A = pA[i], B = pB[i];
+    const u32 C = pC[i];
+    const u32 a = action36[i];
+    const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
+    const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
+    u64 kidA[2], kidB[2];
+    u32 kidC[2];
+    for (u32 bit = 0; bit < 2; ++bit) {
+        u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32), Cc = C;
+        step_core<false>(A0, A1, B0, B1, Cc, act, bit, lut);
+        kidA[bit] = (u64)A0 | ((u64)A1 << 32);
+        kidB[bit] = (u64)B0 | ((u64)B1 << 32);
+        kidC[bit] = Cc;
+    }
+    const u32 n_before = ((u32)(B >> 32) >> B1_N_SHIFT) & 0xFu;
+    const u32 n_after = ((u32)(kidB[0] >> 32) >> B1_N_SHIFT) & 0xFu;
+    const u32 cl_before = ((u32)(B >> 32) >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 cl_after = ((u32)(kidB[0] >> 32) >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 kids = n_after == n_before ? 0u : (cl_after != cl_before ? 2u : 1u);   // mcts.py:245
+    n_children[i] = (uint8_t)kids;
+    c0A[i] = kidA[0]; c0B[i] = kidB[0]; c0C[i] = kidC[0];
+    c1A[i] = kidA[1]; c1B[i] = kidB[1]; c1C[i] = kidC[1];
+    for (u32 c = 0; c < 2; ++c) {
+        int w = -1, t = 0;
+        u64 lm = 0;
+        int64_t k = 0;
+        if (c < kids) {
+            Cold s;
+            cold_unpack(kidA[c], kidB[c], kidC[c], s);
+            cold_update_winner(s, w, t);
+            lm = cold_legal_mask(s);
+            k = cold_py_hash(s);
+        }
+        winner[i * 2 + c] = (int8_t)w;
+        terminal[i * 2 + c] = (uint8_t)t;
+        legal[i * 2 + c] = lm;
+        key[i * 2 + c] = k;
+    }
+}
+
+// MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
+// random moves to the end with the board in registers.  Ply p uses the counter hash of
+// (seed, board id, step_idx0 + p) exactly like qttt_sample_actions + qttt_step would.
+__global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
+    const u64 *pA, const u64 *pB, const u32 *pC, u64 seed, u32 step_idx0, u64 board_offset,
+    int8_t *result, uint8_t *plies, u64 *fA, u64 *fB, u32 *fC, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
+    fill_line_lut(lut);
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 A = pA[i], B = pB[i];
+    u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32), C = pC[i];
+    const u32 id = fold_id(board_offset + (u64)i);
+    u32 played = 0;
+    for (u32 p = 0; p < 9u; ++p) {
+        const u32 cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
+        const u32 empty = ~cl & 0x1FFu;
+        const u32 e = (u32)__builtin_popcount(empty);
+        if ((B1 >> 31) || e < 2u) break;                  // terminal (mcts.py:188) or nothing legal
+        const u64 key = launch_key(seed, step_idx0 + p);
+        const u32 h1 = lowbias32(id ^ (u32)key);
+        const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+        u32 k = __umulhi(h2, e * (e - 1u) / 2u);
+        u32 lo = 0, hi = 0, rest = empty, left = e;
+        for (int it = 0; it < 9; ++it) {
+            const u32 v = (u32)__builtin_ctz(rest);
+            rest &= rest - 1u;
+            left -= 1u;
+            if (k < left) {
+                lo = v;
+                u32 rr = rest;
+                for (u32 jj = 0; jj < k; ++jj) rr &= rr - 1u;
+                hi = (u32)__builtin_ctz(rr);
+                break;
+            }
+            k -= left;
+        }
+        step_core<false>(A0, A1, B0, B1, C, lo | (hi << 8), h1 >> 31, lut);
+        played += 1u;
+    }
+    const u64 oA = (u64)A0 | ((u64)A1 << 32), oB = (u64)B0 | ((u64)B1 << 32);
+    Cold s;
+    cold_unpack(oA, oB, C, s);
+    int w, t;
+    cold_update_winner(s, w, t);
+    result[i] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));       // MCTS._reward, mcts.py:200-209
+    plies[i] = (uint8_t)played;
+    if (fA) { fA[i] = oA; fB[i] = oB; fC[i] = C; }
+}
+
+// GameState.to_vector (mcts.py:67-85) as f32[18][10] and action_mask (mcts.py:87-91)
+__global__ __launch_bounds__(QTTT_BLOCK) void encode_kernel(
+    const u64 *pA, const u64 *pB, const u32 *pC, float *vec, uint8_t *mask, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_unpack(pA[i], pB[i], pC[i], s);
+    float *o = vec + i * 180;
+    u32 qsets = 0;
+    for (u32 k = 0; k < 4; ++k) qsets |= s.comps[k];
+    for (u32 v = 0; v < 9; ++v) {
+        const u32 col = (s.cl >> v & 1u) ? s.sq[v] : 9u;            // board -1 indexes column 9
+        u32 touched = 0;                                           // rounds whose move touches v
+        for (u32 t = 0; t < s.n; ++t)
+            if ((s.mv[t] & 0xFu) == v || (s.mv[t] >> 4) == v) touched |= 1u << t;
+        for (u32 c = 0; c < 10; ++c) {
+            o[v * 10 + c] = c == col ? 1.0f : 0.0f;
+            float q = (touched >> c & 1u) ? (1.0f / 3.0f) : 0.0f;  // 1/math.sqrt(9)
+            if (c == 9u && !(qsets >> v & 1u)) q = 1.0f;           // square in no qstruct
+            o[90 + v * 10 + c] = q;
+        }
+    }
+    if (mask) {
+        const u64 lm = cold_legal_mask(s);
+        for (int a = 0; a < 36; ++a) mask[i * 36 + a] = (uint8_t)(lm >> a & 1ull);
+    }
+}
+
+
 // tuning knob (bench / profiling): boards per lane of the step kernel (1|2|4).  Initialised from
 // QTTT_STEP_BPL, changeable at run time through qttt_set_tuning().
 inline int &tuning_bpl() {
@@ -720,6 +929,54 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int
     hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0,
                        (hipStream_t)stream, p.B, (u32)key, (u32)(key >> 32), (u64)board_offset,
                        (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), actions, n);
+    return launch_status();
+}
+
+int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                   int64_t *key, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !winner || !terminal || !legal || !key) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    hipLaunchKernelGGL(node_info_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, p.C, winner, terminal, (u64 *)legal, key, n);
+    return launch_status();
+}
+
+int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *child1,
+                uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                int64_t *key, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !action36 || !child0 || !child1 || !n_children || !winner || !terminal || !legal || !key)
+        return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
+    hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, p.C, action36, c0.A, c0.B, c0.C, c1.A, c1.B, c1.C, n_children, winner,
+                       terminal, (u64 *)legal, key, n);
+    return launch_status();
+}
+
+int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
+                 int8_t *result, uint8_t *plies, void *final_state, int64_t n, void *stream) {
+    if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !result || !plies) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    Planes f = {nullptr, nullptr, nullptr};
+    if (final_state) f = planes(final_state, n);
+    hipLaunchKernelGGL(rollout_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, p.C, (u64)seed, step_idx0, (u64)board_offset, result, plies, f.A, f.B, f.C, n);
+    return launch_status();
+}
+
+int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !vec) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    hipLaunchKernelGGL(encode_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, p.C, vec, mask, n);
     return launch_status();
 }
 

@@ -220,6 +220,94 @@ class VecEnv:
         _native.check(rc, "qttt_sample_actions")
         return out
 
+    # ------------------------------------------------------------------ MCTS-side rows
+    @classmethod
+    def from_state(cls, state, num_envs, seed=0, auto_reset=False, board_offset=0):
+        """Wraps an existing packed state tensor (e.g. a child buffer written by expand())."""
+        env = cls.__new__(cls)
+        env.num_envs = int(num_envs)
+        env.device = state.device
+        env._lib = _native.lib()
+        if state.dtype != torch.uint8 or state.numel() != env._lib.qttt_state_bytes(env.num_envs):
+            raise ValueError("state must be a uint8 tensor of qttt_state_bytes(num_envs) bytes")
+        env.seed, env.auto_reset, env.board_offset, env.step_idx = int(seed), bool(auto_reset), int(board_offset), 0
+        env.action_space = reference_action_space()
+        env.observation_space = reference_observation_space()
+        env.state = state
+        n = env.num_envs
+        with torch.cuda.device(env.device):
+            env._reward = torch.empty(n, dtype=torch.float32, device=env.device)
+            env._terminated = torch.empty(n, dtype=torch.bool, device=env.device)
+            env._truncated = torch.zeros(n, dtype=torch.bool, device=env.device)
+        return env
+
+    def node_info(self):
+        """GameState bookkeeping per board (mcts.py:20-27,52-65,93-94): winner i8 (1/0/-1 = True/
+        False/None), terminal bool, legal int64 (bit a = action a legal), key int64 (= Python's
+        hash(tuple(board)+tuple(moves)))."""
+        n, dev = self.num_envs, self.device
+        with torch.cuda.device(dev):
+            winner = torch.empty(n, dtype=torch.int8, device=dev)
+            terminal = torch.empty(n, dtype=torch.bool, device=dev)
+            legal = torch.empty(n, dtype=torch.int64, device=dev)
+            key = torch.empty(n, dtype=torch.int64, device=dev)
+            rc = self._lib.qttt_node_info(self.state.data_ptr(), winner.data_ptr(), terminal.data_ptr(),
+                                          legal.data_ptr(), key.data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_node_info")
+        return {"winner": winner, "terminal": terminal, "legal": legal, "key": key}
+
+    def expand(self, action36):
+        """MCTS._step (mcts.py:233-267) for every board: action36 u8[N] (ind2move index).
+        Returns dict(child0, child1 = VecEnv over the child states, n_children u8[N],
+        winner i8[N,2], terminal bool[N,2], legal int64[N,2], key int64[N,2])."""
+        n, dev = self.num_envs, self.device
+        a = torch.as_tensor(action36).to(torch.uint8).to(dev).contiguous()
+        if a.shape != (n,):
+            raise ValueError("action36 must have shape (%d,)" % n)
+        with torch.cuda.device(dev):
+            c0 = torch.empty_like(self.state)
+            c1 = torch.empty_like(self.state)
+            nch = torch.empty(n, dtype=torch.uint8, device=dev)
+            winner = torch.empty((n, 2), dtype=torch.int8, device=dev)
+            terminal = torch.empty((n, 2), dtype=torch.bool, device=dev)
+            legal = torch.empty((n, 2), dtype=torch.int64, device=dev)
+            key = torch.empty((n, 2), dtype=torch.int64, device=dev)
+            rc = self._lib.qttt_expand(self.state.data_ptr(), a.data_ptr(), c0.data_ptr(), c1.data_ptr(),
+                                       nch.data_ptr(), winner.data_ptr(), terminal.data_ptr(),
+                                       legal.data_ptr(), key.data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_expand")
+        mk = lambda st: VecEnv.from_state(st, n, seed=self.seed, board_offset=self.board_offset)
+        return {"child0": mk(c0), "child1": mk(c1), "n_children": nch, "winner": winner,
+                "terminal": terminal, "legal": legal, "key": key}
+
+    def rollout(self, step_idx0=None, return_final=False):
+        """MCTS._simulate (mcts.py:185-198) under uniform priors: one fused random playout per
+        board, boards unchanged.  Returns (result i8[N] in {+1,-1,0}, plies u8[N][, final VecEnv])."""
+        n, dev = self.num_envs, self.device
+        if step_idx0 is None:
+            step_idx0 = self.step_idx
+        with torch.cuda.device(dev):
+            result = torch.empty(n, dtype=torch.int8, device=dev)
+            plies = torch.empty(n, dtype=torch.uint8, device=dev)
+            final = torch.empty_like(self.state) if return_final else None
+            rc = self._lib.qttt_rollout(self.state.data_ptr(), self.seed, int(step_idx0), self.board_offset,
+                                        result.data_ptr(), plies.data_ptr(), _ptr(final), n, self._stream())
+        _native.check(rc, "qttt_rollout")
+        if return_final:
+            return result, plies, VecEnv.from_state(final, n, seed=self.seed, board_offset=self.board_offset)
+        return result, plies
+
+    def encode(self, with_mask=True):
+        """GameState.to_vector (mcts.py:67-85) as f32[N,18,10] and action_mask (mcts.py:87-91) as
+        bool[N,36], without leaving the GPU."""
+        n, dev = self.num_envs, self.device
+        with torch.cuda.device(dev):
+            vec = torch.empty((n, 18, 10), dtype=torch.float32, device=dev)
+            mask = torch.empty((n, 36), dtype=torch.bool, device=dev) if with_mask else None
+            rc = self._lib.qttt_encode(self.state.data_ptr(), vec.data_ptr(), _ptr(mask), n, self._stream())
+        _native.check(rc, "qttt_encode")
+        return (vec, mask) if with_mask else vec
+
     # ------------------------------------------------------------------ checkpointing
     def state_dict(self):
         return {"state": self.state.clone(), "seed": self.seed, "step_idx": self.step_idx,
