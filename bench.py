@@ -95,11 +95,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; QTTT_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (plumbing only)
+    backend = os.environ.get("QTTT_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     B, K, W = args.boards, args.steps, args.warmup
     T = K + W
@@ -119,7 +126,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     # ---- timed: replay --------------------------------------------------------------
     env.reset()
@@ -148,11 +158,11 @@ def main():
     replay_ok = bool(torch.equal(env.state, final_state))
 
     if world > 1:
-        tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
         # episode counters: the only exchange in the design, once per run, off the timed path
-        cnt = torch.stack([term_count, win_count])
+        cnt = torch.stack([term_count, win_count]).to(coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         term_count, win_count = cnt[0], cnt[1]
 

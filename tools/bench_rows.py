@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Timing of the SURVEY §8(f) rows beside the headline bench (not the judged line):
+batched expand at BASELINE config 5's batch (65 536), fused rollout and encode at 1 048 576.
+Prints one JSON object per row."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from qtttgym_amd import VecEnv  # noqa: E402
+
+
+def timed(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def midgame(n, plies, seed=1):
+    env = VecEnv(n, seed=seed)
+    for _ in range(plies):
+        env.step_raw(env.sample_actions())
+    return env
+
+
+def main():
+    out = []
+    # expand: read 20 B + 1 B, write 2 x 20 B + 1 + 2 + 2 + 16 + 16 = 78 B per pair
+    n = 65536
+    env = midgame(n, 4)
+    act = torch.randint(0, 36, (n,), dtype=torch.uint8, device="cuda")
+    # time the raw ABI call with preallocated outputs
+    L, st = env._lib, env.state
+    c0, c1 = torch.empty_like(st), torch.empty_like(st)
+    nch = torch.empty(n, dtype=torch.uint8, device="cuda")
+    w = torch.empty((n, 2), dtype=torch.int8, device="cuda")
+    tm = torch.empty((n, 2), dtype=torch.bool, device="cuda")
+    lg = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+    ky = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    t = timed(lambda: L.qttt_expand(st.data_ptr(), act.data_ptr(), c0.data_ptr(), c1.data_ptr(), nch.data_ptr(),
+                                    w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr(), n, s))
+    out.append({"row": "expand", "boards": n, "us": t * 1e6, "expansions_per_s": n / t,
+                "reference_cpu_step_calls_per_s": 4900})
+    for n in (65536, 1 << 20):
+        env = midgame(n, 0)
+        res = torch.empty(n, dtype=torch.int8, device="cuda")
+        pl = torch.empty(n, dtype=torch.uint8, device="cuda")
+        t = timed(lambda: env._lib.qttt_rollout(env.state.data_ptr(), 1, 0, 0, res.data_ptr(), pl.data_ptr(), 0, n, s))
+        plies = float(pl.float().mean())
+        out.append({"row": "rollout_from_empty_board", "boards": n, "us": t * 1e6, "playouts_per_s": n / t,
+                    "mean_plies": plies, "env_steps_per_s": n * plies / t})
+    n = 1 << 20
+    env = midgame(n, 5)
+    vec = torch.empty((n, 18, 10), dtype=torch.float32, device="cuda")
+    mask = torch.empty((n, 36), dtype=torch.bool, device="cuda")
+    t = timed(lambda: env._lib.qttt_encode(env.state.data_ptr(), vec.data_ptr(), mask.data_ptr(), n, s))
+    out.append({"row": "encode", "boards": n, "us": t * 1e6, "boards_per_s": n / t,
+                "output_GBps": n * (720 + 36) / t / 1e9})
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()

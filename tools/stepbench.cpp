@@ -23,27 +23,49 @@ typedef unsigned int u32;
 
 template <typename T, int N> struct alignas(sizeof(T) * N) Vec { T v[N]; };
 
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+template <int B> struct RawOf;
+template <> struct RawOf<1> { typedef uint8_t type; };
+template <> struct RawOf<2> { typedef uint16_t type; };
+template <> struct RawOf<4> { typedef u32 type; };
+template <> struct RawOf<8> { typedef u32x2 type; };
+template <> struct RawOf<16> { typedef u32x4 type; };
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+template <> struct RawOf<32> { typedef u32x8 type; };
+template <typename V> __device__ __forceinline__ V ld_nt(const V *p) {
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+    V v; __builtin_memcpy(&v, &r, sizeof(V)); return v;
+}
+template <typename V> __device__ __forceinline__ void st_nt(V *p, const V &v) {
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r; __builtin_memcpy(&r, &v, sizeof(V));
+    __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+}
+
+// same loads and stores as the step kernel (non-temporal, like the product), trivial arithmetic
 template <int BPL>
 __global__ __launch_bounds__(256) void floor_kernel(u64 *pA, u64 *pB, u32 *pC, const uint16_t *actions,
                                                     u32 *reward, uint8_t *term, int64_t n_groups) {
     int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n_groups) return;
     int64_t i0 = j * BPL;
-    Vec<u64, BPL> a = *reinterpret_cast<const Vec<u64, BPL> *>(pA + i0);
-    Vec<u64, BPL> b = *reinterpret_cast<const Vec<u64, BPL> *>(pB + i0);
-    Vec<u32, BPL> c = *reinterpret_cast<const Vec<u32, BPL> *>(pC + i0);
-    Vec<uint16_t, BPL> act = *reinterpret_cast<const Vec<uint16_t, BPL> *>(actions + i0);
+    Vec<u64, BPL> a = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pA + i0));
+    Vec<u64, BPL> b = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pB + i0));
+    Vec<u32, BPL> c = ld_nt(reinterpret_cast<const Vec<u32, BPL> *>(pC + i0));
+    Vec<uint16_t, BPL> act = ld_nt(reinterpret_cast<const Vec<uint16_t, BPL> *>(actions + i0));
     Vec<u32, BPL> rw; Vec<uint8_t, BPL> tm;
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
         a.v[k] ^= act.v[k]; b.v[k] += 1; c.v[k] ^= 1u;
         rw.v[k] = (u32)a.v[k]; tm.v[k] = (uint8_t)b.v[k];
     }
-    *reinterpret_cast<Vec<u64, BPL> *>(pA + i0) = a;
-    *reinterpret_cast<Vec<u64, BPL> *>(pB + i0) = b;
-    *reinterpret_cast<Vec<u32, BPL> *>(pC + i0) = c;
-    *reinterpret_cast<Vec<u32, BPL> *>(reward + i0) = rw;
-    *reinterpret_cast<Vec<uint8_t, BPL> *>(term + i0) = tm;
+    st_nt(reinterpret_cast<Vec<u64, BPL> *>(pA + i0), a);
+    st_nt(reinterpret_cast<Vec<u64, BPL> *>(pB + i0), b);
+    st_nt(reinterpret_cast<Vec<u32, BPL> *>(pC + i0), c);
+    st_nt(reinterpret_cast<Vec<u32, BPL> *>(reward + i0), rw);
+    st_nt(reinterpret_cast<Vec<uint8_t, BPL> *>(term + i0), tm);
 }
 
 struct Lib {
