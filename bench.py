@@ -76,8 +76,8 @@ def cpu_baseline(actions_host, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +184,7 @@ def main():
                        "episodes_finished": int(term_count), "steps_with_line": int(win_count)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(B),
-                         "kernel": "step_kernel<false,true>", "launch_us": launch_s * 1e6,
+                         "kernel": "step_kernel<2,false,true>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * B},
         }
         if not args.no_cpu_baseline:
