@@ -212,3 +212,35 @@ def test_distribution_sanity_uniform_policy():
     assert not bool(alive.any())
     mean_len = float(length.float().mean())
     assert abs(mean_len - 8.30) < 0.05, mean_len
+
+
+def test_steps_are_hip_graph_capturable():
+    """qttt_step never allocates, syncs or queries (include/qttt.h conventions), so a rollout loop
+    can be captured into a HIP graph on the caller's stream and replayed: same results as eager."""
+    from qtttgym_amd import VecEnv
+    n, T, seed = 4096, 12, 31
+    rec = VecEnv(n, seed=seed, auto_reset=True)
+    actions = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        rec.sample_actions(out=actions[t])
+        rec.step_raw(actions[t])
+    want = rec.state.clone()
+    env = VecEnv(n, seed=seed, auto_reset=True)
+    reward = torch.empty((T, n), dtype=torch.float32, device="cuda")
+    term = torch.empty((T, n), dtype=torch.bool, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        env.step_many(actions[:1])            # warm the stream / kernels outside capture
+        env.reset()
+        with torch.cuda.graph(g, stream=side):
+            env.step_many(actions, reward=reward, terminated=term)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):                        # replay twice from a fresh reset: identical both times
+        env.reset()
+        reward.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(env.state, want)
+    assert int(term.sum()) > 0 and bool((reward.view(torch.int32) < 0).all())
