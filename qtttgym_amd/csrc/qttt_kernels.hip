@@ -564,40 +564,64 @@ __global__ __launch_bounds__(QTTT_BLOCK) void import_kernel(
     pC[i] = C;
 }
 
+// ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
+// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4;
+// nth_bit[m][r]: index of the r-th set bit of the 9-bit mask m.  The k-th legal action of a board
+// with empty-square mask m is (nth_bit[m][i], nth_bit[m][j]).
+struct PolicyLut {
+    uint8_t rank_pair[10 * 36];
+    uint8_t nth_bit[512 * 9];
+    uint8_t pad[4];
+    constexpr PolicyLut() : rank_pair(), nth_bit(), pad() {
+        for (int e = 0; e < 10; ++e) {
+            int k = 0;
+            for (int i = 0; i < e; ++i)
+                for (int j = i + 1; j < e; ++j) rank_pair[e * 36 + k++] = (uint8_t)(i | (j << 4));
+            for (; k < 36; ++k) rank_pair[e * 36 + k] = 0;
+        }
+        for (int m = 0; m < 512; ++m) {
+            int r = 0;
+            for (int v = 0; v < 9; ++v)
+                if (m >> v & 1) nth_bit[m * 9 + r++] = (uint8_t)v;
+            for (; r < 9; ++r) nth_bit[m * 9 + r] = 0;
+        }
+    }
+};
+__constant__ PolicyLut g_policy_lut = PolicyLut();
+constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 512 * 9 + 4) / 4;
+
+__device__ inline void fill_policy_lut(uint8_t *dst) {
+    const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
+    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += QTTT_BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
+}
+
+// the policy's action for a board whose empty-square mask is `empty`, from hash word h2: lo | hi<<8
+__device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32 h2) {
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 k = __umulhi(h2, (e * (e - 1u)) >> 1);
+    const u32 ij = plut[e * 36u + k];
+    const uint8_t *nth = plut + 360u + empty * 9u;
+    return (u32)nth[ij & 0xFu] | ((u32)nth[ij >> 4] << 8);
+}
+
 // legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
 __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
-    const u64 *pB, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint8_t *actions,
+    const u64 *pB, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint16_t *actions,
     int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    fill_policy_lut(plut);
+    __syncthreads();
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const u32 B1 = (u32)(pB[i] >> 32);
     const u32 cl = (auto_reset && (B1 >> 31)) ? 0u : (B1 >> B1_CL_SHIFT) & 0x1FFu;
     const u32 empty = ~cl & 0x1FFu;
-    const u32 e = (u32)__builtin_popcount(empty);
-    const u32 n_legal = e * (e - 1u) / 2u;
-    u32 lo = 0, hi = 0;
-    if (n_legal != 0u) {
-        const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
-        const u32 h2 = lowbias32(h1 ^ key_hi);
-        u32 k = __umulhi(h2, n_legal);
-        // the j-th empty square (ascending) pairs with the e-1-j later ones
-        u32 rest = empty, left = e;
-        for (int it = 0; it < 9; ++it) {
-            const u32 v = (u32)__builtin_ctz(rest);
-            rest &= rest - 1u;
-            left -= 1u;
-            if (k < left) {
-                lo = v;
-                u32 rr = rest;
-                for (u32 jj = 0; jj < k; ++jj) rr &= rr - 1u;
-                hi = (u32)__builtin_ctz(rr);
-                break;
-            }
-            k -= left;
-        }
-    }
-    actions[i * 2] = (uint8_t)lo;
-    actions[i * 2 + 1] = (uint8_t)hi;
+    const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
+    const u32 h2 = lowbias32(h1 ^ key_hi);
+    // fewer than two empty squares: rank_pair gives (0,0) and nth_bit[..][0] twice -> a == b, a noop;
+    // the spec says (0,0)
+    const u32 act = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
+    actions[i] = (uint16_t)act;
 }
 
 // ====================================================================== §8(f) rows
@@ -737,7 +761,9 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, u64 seed, u32 step_idx0, u64 board_offset,
     int8_t *result, uint8_t *plies, u64 *fA, u64 *fB, u32 *fC, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[512];
-    fill_line_lut(lut);
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    fill_policy_lut(plut);
+    fill_line_lut(lut);                                   // ends with the workgroup barrier
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const u64 A = pA[i], B = pB[i];
@@ -745,29 +771,12 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     const u32 id = fold_id(board_offset + (u64)i);
     u32 played = 0;
     for (u32 p = 0; p < 9u; ++p) {
-        const u32 cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
-        const u32 empty = ~cl & 0x1FFu;
-        const u32 e = (u32)__builtin_popcount(empty);
-        if ((B1 >> 31) || e < 2u) break;                  // terminal (mcts.py:188) or nothing legal
+        const u32 empty = ~(B1 >> B1_CL_SHIFT) & 0x1FFu;
+        if ((B1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
         const u64 key = launch_key(seed, step_idx0 + p);
         const u32 h1 = lowbias32(id ^ (u32)key);
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
-        u32 k = __umulhi(h2, e * (e - 1u) / 2u);
-        u32 lo = 0, hi = 0, rest = empty, left = e;
-        for (int it = 0; it < 9; ++it) {
-            const u32 v = (u32)__builtin_ctz(rest);
-            rest &= rest - 1u;
-            left -= 1u;
-            if (k < left) {
-                lo = v;
-                u32 rr = rest;
-                for (u32 jj = 0; jj < k; ++jj) rr &= rr - 1u;
-                hi = (u32)__builtin_ctz(rr);
-                break;
-            }
-            k -= left;
-        }
-        step_core<false>(A0, A1, B0, B1, C, lo | (hi << 8), h1 >> 31, lut);
+        step_core<false>(A0, A1, B0, B1, C, policy_action(plut, empty, h2), h1 >> 31, lut);
         played += 1u;
     }
     const u64 oA = (u64)A0 | ((u64)A1 << 32), oB = (u64)B0 | ((u64)B1 << 32);
@@ -1009,11 +1018,12 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int
     if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state || !actions) return QTTT_ERR_NULL;
+    if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // written as u16 pairs
     Planes p = planes(const_cast<void *>(state), n);
     const u64 key = launch_key(seed, step_idx);
     hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0,
                        (hipStream_t)stream, p.B, (u32)key, (u32)(key >> 32), (u64)board_offset,
-                       (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), actions, n);
+                       (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), reinterpret_cast<uint16_t *>(actions), n);
     return launch_status();
 }
 
