@@ -67,3 +67,35 @@ def test_known_answer_traces(golden):
     k1, k2 = kind.index("K1"), kind.index("K2")
     assert golden["board"][k1, 1, :2].tolist() == [1, 0]
     assert golden["board"][k2, 1, :2].tolist() == [0, 1]
+
+
+def test_oracle_state_invariants_under_random_play():
+    """SURVEY.md §4 invariants, on 20 000 fresh random episodes of the oracle: rounds on the board
+    are distinct, qstructs are disjoint node sets of the forest of un-collapsed moves (<= 4 of
+    them, each >= 2 squares), <= 9 moves, autofill round is always 8, reward in {-0.0, -1.0}."""
+    n, seed = 20000, 77
+    ob = oracle.OracleBoards(n)
+    rng = np.random.default_rng(seed)
+    for t in range(10):
+        a = ob.sample_actions(seed, t)
+        reward, term = ob.step(a, rng.integers(0, 2, n).astype(np.uint8))
+        assert set(np.unique(reward.view(np.uint32))) <= {0x80000000, 0xBF800000}
+        board, nm, q, nq = ob.board, ob.b["n_moves"], ob.qmask, ob.b["n_q"]
+        assert nm.max() <= 9 and nq.max() <= 4
+        for i in range(0, n, 97):
+            rounds = [int(r) for r in board[i] if r >= 0]
+            assert len(rounds) == len(set(rounds))
+            live = [(int(ob.b["moves"][i][j][0]), int(ob.b["moves"][i][j][1])) for j in range(int(nm[i]))
+                    if j not in rounds]
+            nodes = set(x for m in live for x in m)
+            masks = [int(q[i][k]) for k in range(int(nq[i]))]
+            union = 0
+            for m in masks:
+                assert bin(m).count("1") >= 2 and (union & m) == 0
+                union |= m
+            assert union == sum(1 << x for x in nodes)
+            assert len(live) == len(nodes) - len(masks)            # a forest: edges = nodes - trees
+            for j in range(int(nm[i])):
+                lo, hi = int(ob.b["moves"][i][j][0]), int(ob.b["moves"][i][j][1])
+                if lo == hi:
+                    assert j == 8 and int(board[i][lo]) == 8       # autofill is always round 8

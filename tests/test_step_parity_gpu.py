@@ -244,3 +244,25 @@ def test_steps_are_hip_graph_capturable():
         torch.cuda.synchronize()
         assert torch.equal(env.state, want)
     assert int(term.sum()) > 0 and bool((reward.view(torch.int32) < 0).all())
+
+
+def test_two_million_boards_counters_vs_oracle():
+    """BASELINE config 4's total (2 097 152 boards, here on one GPU): episode counters and the
+    final reference-visible state against the oracle."""
+    from qtttgym_amd import VecEnv
+    from qtttgym_amd.dist import EpisodeCounters
+    n, seed = 1 << 21, 8
+    env = VecEnv(n, seed=seed, auto_reset=True)
+    ob = oracle.OracleBoards(n)
+    cnt = EpisodeCounters("cuda")
+    fin = lines = 0
+    for t in range(10):
+        a = env.sample_actions()
+        r, tm = env.step_raw(a)
+        cnt.update(r, tm)
+        r_o, t_o = ob.step(_np(a), None, seed, t, 0, True)
+        fin += int(t_o.sum())
+        lines += int(((r_o != 0) & (t_o != 0)).sum())
+    c = cnt.all_reduce().tolist()
+    assert c == [fin, lines, fin - lines, 10 * n]
+    assert_same_as_oracle(env, ob)
