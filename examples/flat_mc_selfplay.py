@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Batched search on top of the §8(f) rows: G simultaneous games, the mover picks its action by
+flat Monte-Carlo — expand every one of the 36 actions for every game (qttt_expand, both collapse
+branches), run S fused random playouts from every child (qttt_rollout), average, take the best.
+One search sweep touches G*36*2 children and G*36*2*S playouts without leaving the GPU — the
+"env as rollout backend" use BASELINE.json's config 5 has in mind (G*36 = 65 536 at G = 1820).
+
+    python examples/flat_mc_selfplay.py [--games 1024] [--sims 16]
+
+Player 1 (X) searches, player 2 (O) plays the uniform-legal random policy; prints P1's score.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qtttgym_amd import VecEnv  # noqa: E402
+
+PAIRS = torch.tensor([(i, j) for i in range(9) for j in range(i + 1, 9)], dtype=torch.uint8)  # ind2move
+
+
+def search_actions(env, sims, sweep):
+    """Best action36 per game for the side to move (as P1: maximise the playout result)."""
+    G, dev = env.num_envs, env.device
+    # one row per (game, action): replicate the G states 36 times along the board axis
+    ex = env.export_boards()
+    rep = VecEnv(G * 36, device=dev, seed=env.seed + 1000 + sweep)
+    rep.import_boards(*(ex[k].repeat_interleave(36, dim=0) for k in ("moves", "n_moves", "board", "qmask", "n_q")))
+    act = torch.arange(36, dtype=torch.uint8, device=dev).repeat(G)
+    out = rep.expand(act)
+    nch = out["n_children"].to(torch.float32)                       # 0 illegal, 1, or 2 (collapse)
+    value = torch.zeros(G * 36, device=dev)
+    for c, child in enumerate((out["child0"], out["child1"])):
+        tot = torch.zeros(G * 36, device=dev)
+        for s in range(sims):
+            r, _ = child.rollout(step_idx0=100 + 16 * (sweep * sims + s))
+            tot += r.to(torch.float32)
+        value += torch.where(nch > c, tot / sims, torch.zeros_like(tot))
+    value = value / nch.clamp(min=1)                                # both collapse branches equally likely
+    value = torch.where(nch > 0, value, torch.full_like(value, -2.0))
+    return value.view(G, 36).argmax(dim=1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=1024)
+    ap.add_argument("--sims", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    G = args.games
+    env = VecEnv(G, seed=args.seed)
+    pairs = PAIRS.to(env.device)
+    finished = torch.zeros(G, dtype=torch.bool, device=env.device)
+    for ply in range(9):
+        if ply % 2 == 0:
+            a36 = search_actions(env, args.sims, ply)
+            actions = pairs[a36.long()]
+        else:
+            actions = env.sample_actions()
+        actions = torch.where(finished[:, None], torch.full_like(actions, 255), actions)   # freeze finished games
+        _, term = env.step_raw(actions.contiguous())
+        finished |= term
+    info = env.node_info()
+    w = info["winner"]
+    p1, p2, none = int((w == 1).sum()), int((w == 0).sum()), int((w == -1).sum())
+    print("games %d  sims/child %d :  P1 (flat MC) wins %d (%.1f %%), P2 (random) wins %d, no winner %d"
+          % (G, args.sims, p1, 100.0 * p1 / G, p2, none))
+    return p1 / G
+
+
+if __name__ == "__main__":
+    main()
