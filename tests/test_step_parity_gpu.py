@@ -266,3 +266,34 @@ def test_two_million_boards_counters_vs_oracle():
     c = cnt.all_reduce().tolist()
     assert c == [fin, lines, fin - lines, 10 * n]
     assert_same_as_oracle(env, ob)
+
+
+def test_misaligned_caller_buffers_fall_back_to_narrower_accesses():
+    """The vector width of the step kernel follows the alignment of the caller's pointers
+    (include/qttt.h): views offset by one board (2 / 4 / 1 bytes) must give the same results."""
+    from qtttgym_amd import VecEnv, _native
+    n, seed = 1000, 3
+    env = VecEnv(n, seed=seed)
+    ref = VecEnv(n, seed=seed)
+    L = _native.lib()
+    big_a = torch.zeros((n + 1, 2), dtype=torch.uint8, device="cuda")
+    big_r = torch.zeros(n + 1, dtype=torch.float32, device="cuda")
+    big_t = torch.zeros(n + 1, dtype=torch.bool, device="cuda")
+    big_b = torch.zeros(n + 1, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for t in range(10):
+        a = ref.sample_actions()
+        bits = torch.randint(0, 2, (n,), dtype=torch.uint8, device="cuda")
+        r_ref, t_ref = ref.step_raw(a, bits)
+        big_a[1:] = a
+        big_b[1:] = bits
+        rc = L.qttt_step(env.state.data_ptr(), big_a[1:].data_ptr(), big_b[1:].data_ptr(), seed, t, 0, 0,
+                         big_r[1:].data_ptr(), big_t[1:].data_ptr(), n, s)
+        assert rc == 0
+        assert torch.equal(big_r[1:].view(torch.int32), r_ref.view(torch.int32))
+        assert torch.equal(big_t[1:], t_ref)
+        assert torch.equal(env.state, ref.state)
+    # an odd actions address cannot be read as u16 pairs at all
+    odd = torch.zeros(2 * n + 1, dtype=torch.uint8, device="cuda")
+    assert L.qttt_step(env.state.data_ptr(), odd[1:].data_ptr(), None, 0, 0, 0, 0, big_r.data_ptr(),
+                       big_t.data_ptr(), n, s) == -3
