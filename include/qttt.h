@@ -35,6 +35,10 @@ extern "C" {
                                      re-initialised before the action is applied (the build's
                                      throughput mode; the reference has no auto-reset) */
 
+#define QTTT_FLAG_FUSED 2u        /* qttt_step_many only: run the n_steps steps in ONE launch with the
+                                     boards held in registers (same results; for replay / evaluation
+                                     where all actions are known up front) */
+
 int     qttt_abi_version(void);
 /* bytes of device memory needed for n boards */
 int64_t qttt_state_bytes(int64_t n);
@@ -60,7 +64,8 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
 /* n_steps consecutive qttt_step launches enqueued back to back from C, so a replay / rollout
  * loop is not paced by the host interpreter.  Step t (0-based) reads actions + t*2n and
  * bits + t*n (when bits != NULL), uses step_idx0 + t, and writes reward + t*out_stride and
- * terminated + t*out_stride (out_stride 0: every step overwrites the same n outputs). */
+ * terminated + t*out_stride (out_stride 0: every step overwrites the same n outputs; with
+ * QTTT_FLAG_FUSED only the last step's outputs are then written). */
 int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
                    uint32_t step_idx0, int64_t board_offset, uint32_t flags, float *reward,
                    uint8_t *terminated, int64_t out_stride, int64_t n, int32_t n_steps,

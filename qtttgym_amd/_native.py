@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libqttt_hip.so")
 
 ABI_VERSION = 1
 FLAG_AUTO_RESET = 1
+FLAG_FUSED = 2
 
 # every symbol include/qttt.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,

@@ -139,6 +139,12 @@ struct LineLut {
 };
 __constant__ LineLut g_line_lut = LineLut();
 
+__device__ inline void fill_line_lut(uint8_t *lut) {
+    for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
+        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ counter hash (the build's
 // synthetic-input spec)
 __host__ __device__ inline u32 lowbias32(u32 x) {
@@ -359,6 +365,43 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
     }
 #endif
+}
+
+// T consecutive steps in ONE launch (qttt_step_many with QTTT_FLAG_FUSED): the boards stay in
+// registers, only the per-step streams move (2 B action in, 5 B reward/terminated out per step), so
+// the loop is VALU-bound and pays one launch instead of T.  Same results as T launches of
+// step_kernel; meant for replay / evaluation where the actions are known up front (a policy that
+// looks at the state between steps needs the one-launch-per-step form).
+template <bool HAS_BITS, bool AUTO_RESET>
+__global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
+    u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
+    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u64 seed, u32 step_idx0,
+    u32 id_hi_fold, u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    int64_t out_stride, int64_t n, int32_t n_steps) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
+    fill_line_lut(lut);
+    const int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 A = pA[i], B = pB[i];
+    u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32), C = pC[i];
+    const u32 id = id_base + (u32)i;
+    u32 win = 0;
+    for (int32_t t = 0; t < n_steps; ++t) {
+        const u32 act = load_stream(&actions[(int64_t)t * n + i]);
+        u32 bit;
+        if (HAS_BITS) bit = load_stream(&bits[(int64_t)t * n + i]) & 1u;
+        else bit = collapse_bit_of(id ^ ((u32)launch_key(seed, step_idx0 + (u32)t) ^ id_hi_fold));
+        win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, act, bit, lut);
+        if (out_stride != 0 || t == n_steps - 1) {
+            const u32 rwv = 0x80000000u | (win << 23);
+            const uint8_t tmv = (uint8_t)(B1 >> 31);
+            store_stream(&reward_bits[(int64_t)t * out_stride + i], rwv);
+            store_stream(&terminated[(int64_t)t * out_stride + i], tmv);
+        }
+    }
+    pA[i] = (u64)A0 | ((u64)A1 << 32);
+    pB[i] = (u64)B0 | ((u64)B1 << 32);
+    pC[i] = C;
 }
 
 // ====================================================================== cold paths
@@ -635,12 +678,6 @@ struct PairLut {
     }
 };
 __constant__ PairLut g_pair_lut = PairLut();
-
-__device__ inline void fill_line_lut(uint8_t *lut) {
-    for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
-        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
-    __syncthreads();
-}
 
 // GameState.actions (mcts.py:20-27): action a is listed iff both its squares are classical-empty
 __device__ inline u64 cold_legal_mask(const Cold &s) {
@@ -960,6 +997,27 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
                    uint8_t *terminated, int64_t out_stride, int64_t n, int32_t n_steps,
                    void *stream) {
     if (n_steps < 0 || out_stride < 0) return QTTT_ERR_SIZE;
+    const u64 first = (u64)(board_offset < 0 ? 0 : board_offset);
+    const bool one_hi = n > 0 && (first >> 32) == ((first + (u64)n - 1u) >> 32);
+    if ((flags & QTTT_FLAG_FUSED) && n > 0 && n_steps > 0 && one_hi) {
+        if (board_offset < 0) return QTTT_ERR_SIZE;
+        if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
+        if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;
+        Planes p = planes(state, n);
+        const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
+        const u32 hi_fold = (u32)(first >> 32) * 0x9E3779B9u;
+        dim3 g(grid_for(n)), b(QTTT_BLOCK);
+        hipStream_t s = (hipStream_t)stream;
+        const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
+        u32 *rb = reinterpret_cast<u32 *>(reward);
+#define QTTT_FUSED(HB, AR)                                                                        \
+    hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.A, p.B, p.C, a16, bits, (u64)seed, \
+                       step_idx0, hi_fold, (u32)first, rb, terminated, out_stride, n, n_steps)
+        if (bits) { if (ar) QTTT_FUSED(true, true); else QTTT_FUSED(true, false); }
+        else      { if (ar) QTTT_FUSED(false, true); else QTTT_FUSED(false, false); }
+#undef QTTT_FUSED
+        return launch_status();
+    }
     for (int32_t t = 0; t < n_steps; ++t) {
         int rc = qttt_step(state, actions + (int64_t)t * 2 * n, bits ? bits + (int64_t)t * n : nullptr,
                            seed, step_idx0 + (uint32_t)t, board_offset, flags,

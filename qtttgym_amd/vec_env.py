@@ -94,10 +94,11 @@ class VecEnv:
         self.step_idx += 1
         return self._reward, self._terminated
 
-    def step_many(self, actions, bits=None, reward=None, terminated=None):
+    def step_many(self, actions, bits=None, reward=None, terminated=None, fused=False):
         """T consecutive steps from pre-recorded device tensors actions u8[T,N,2] (bits u8[T,N]),
         enqueued from C with no per-step host work.  With `reward`/`terminated` of shape [T,N]
-        every step's outputs are kept; otherwise only the last step's (returned)."""
+        every step's outputs are kept; otherwise only the last step's (returned).
+        fused=True runs all T steps in one launch with the boards in registers (same results)."""
         n = self.num_envs
         T = int(actions.shape[0])
         if actions.dtype != torch.uint8 or not actions.is_contiguous() or tuple(actions.shape) != (T, n, 2) \
@@ -117,7 +118,8 @@ class VecEnv:
             r, tm, stride = reward, terminated, n
         with torch.cuda.device(self.device):
             rc = self._lib.qttt_step_many(self.state.data_ptr(), actions.data_ptr(), _ptr(bits), self.seed,
-                                          self.step_idx, self.board_offset, self._flags(), r.data_ptr(),
+                                          self.step_idx, self.board_offset,
+                                          self._flags() | (_native.FLAG_FUSED if fused else 0), r.data_ptr(),
                                           tm.data_ptr(), stride, n, T, self._stream())
         _native.check(rc, "qttt_step_many")
         self.step_idx += T

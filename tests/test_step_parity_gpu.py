@@ -24,6 +24,19 @@ def assert_same_as_oracle(env, ob, tag=""):
     assert np.array_equal(ex["qmask"].view(np.uint16), ob.qmask), tag
 
 
+def _same(got, want, what, t):
+    """array_equal with a report that says where and how much, should it ever fail."""
+    got, want = np.asarray(got), np.asarray(want)
+    if got.shape == want.shape and np.array_equal(got, want):
+        return
+    bad = np.argwhere(got != want) if got.shape == want.shape else None
+    raise AssertionError("%s differs at step %s: shapes %s/%s, %s mismatches, first at %s (got %s want %s)" % (
+        what, t, got.shape, want.shape, None if bad is None else len(bad),
+        None if bad is None or not len(bad) else bad[0].tolist(),
+        None if bad is None or not len(bad) else got[tuple(bad[0])],
+        None if bad is None or not len(bad) else want[tuple(bad[0])]))
+
+
 def test_golden_traces_through_hip(golden):
     from qtttgym_amd import VecEnv
     acts, bits = golden["actions"], golden["bits"]
@@ -34,23 +47,23 @@ def test_golden_traces_through_hip(golden):
                                                   torch.from_numpy(bits[:, t].copy()))
         assert info == {} and not bool(trunc.any())
         ex = {k: _np(v) for k, v in env.export_boards().items()}
-        assert np.array_equal(ex["board"], golden["board"][:, t]), t
-        assert np.array_equal(ex["moves"], golden["moves"][:, t]), t
-        assert np.array_equal(ex["n_moves"], golden["n_moves"][:, t]), t
-        assert np.array_equal(ex["qmask"].view(np.uint16), golden["qmask"][:, t]), t
-        assert np.array_equal(ex["n_q"], golden["n_q"][:, t]), t
+        _same(ex["board"], golden["board"][:, t], "board", t)
+        _same(ex["moves"], golden["moves"][:, t], "moves", t)
+        _same(ex["n_moves"], golden["n_moves"][:, t], "n_moves", t)
+        _same(ex["qmask"].view(np.uint16), golden["qmask"][:, t], "qmask", t)
+        _same(ex["n_q"], golden["n_q"][:, t], "n_q", t)
         want = golden["reward"][:, t].astype(np.float32).view(np.uint32)
-        assert np.array_equal(_np(reward).view(np.uint32), want), t
-        assert np.array_equal(_np(term).astype(np.uint8), golden["terminated"][:, t]), t
-        assert np.array_equal(_np(obs["classical"]), golden["board"][:, t]), t
-        assert np.array_equal(_np(obs["q_states_p1"]), golden["q_p1"][:, t]), t
-        assert np.array_equal(_np(obs["q_states_p1_len"]), golden["q_p1_len"][:, t]), t
-        assert np.array_equal(_np(obs["q_states_p2"]), golden["q_p2"][:, t]), t
-        assert np.array_equal(_np(obs["q_states_p2_len"]), golden["q_p2_len"][:, t]), t
-        assert np.array_equal(_np(obs["turn"]), golden["turn"][:, t]), t
+        _same(_np(reward).view(np.uint32), want, "reward bits", t)
+        _same(_np(term).astype(np.uint8), golden["terminated"][:, t], "terminated", t)
+        _same(_np(obs["classical"]), golden["board"][:, t], "obs.classical", t)
+        _same(_np(obs["q_states_p1"]), golden["q_p1"][:, t], "obs.q_states_p1", t)
+        _same(_np(obs["q_states_p1_len"]), golden["q_p1_len"][:, t], "obs.q_states_p1_len", t)
+        _same(_np(obs["q_states_p2"]), golden["q_p2"][:, t], "obs.q_states_p2", t)
+        _same(_np(obs["q_states_p2_len"]), golden["q_p2_len"][:, t], "obs.q_states_p2_len", t)
+        _same(_np(obs["turn"]), golden["turn"][:, t], "obs.turn", t)
         p1, p2 = env.check_win()
-        assert np.array_equal(_np(p1), golden["p1_round"][:, t]), t
-        assert np.array_equal(_np(p2), golden["p2_round"][:, t]), t
+        _same(_np(p1), golden["p1_round"][:, t], "p1_round", t)
+        _same(_np(p2), golden["p2_round"][:, t], "p2_round", t)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 4096, 262144])
@@ -297,3 +310,30 @@ def test_misaligned_caller_buffers_fall_back_to_narrower_accesses():
     odd = torch.zeros(2 * n + 1, dtype=torch.uint8, device="cuda")
     assert L.qttt_step(env.state.data_ptr(), odd[1:].data_ptr(), None, 0, 0, 0, 0, big_r.data_ptr(),
                        big_t.data_ptr(), n, s) == -3
+
+
+@pytest.mark.parametrize("n", [1000, 65536])
+@pytest.mark.parametrize("with_bits", [False, True])
+def test_fused_step_many_equals_step_by_step(n, with_bits):
+    """QTTT_FLAG_FUSED: T steps in one launch == T launches, every per-step output included."""
+    from qtttgym_amd import VecEnv
+    T, seed = 14, 12
+    rec = VecEnv(n, seed=seed, auto_reset=True, board_offset=5 * n)
+    actions = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+    bits = torch.randint(0, 2, (T, n), dtype=torch.uint8, device="cuda") if with_bits else None
+    r_ref = torch.empty((T, n), dtype=torch.float32, device="cuda")
+    t_ref = torch.empty((T, n), dtype=torch.bool, device="cuda")
+    for t in range(T):
+        rec.sample_actions(out=actions[t])
+        r, tm = rec.step_raw(actions[t], None if bits is None else bits[t])
+        r_ref[t], t_ref[t] = r, tm
+    env = VecEnv(n, seed=seed, auto_reset=True, board_offset=5 * n)
+    r_f = torch.zeros((T, n), dtype=torch.float32, device="cuda")
+    t_f = torch.zeros((T, n), dtype=torch.bool, device="cuda")
+    env.step_many(actions, bits, reward=r_f, terminated=t_f, fused=True)
+    assert torch.equal(env.state, rec.state)
+    assert torch.equal(r_f.view(torch.int32), r_ref.view(torch.int32)) and torch.equal(t_f, t_ref)
+    env2 = VecEnv(n, seed=seed, auto_reset=True, board_offset=5 * n)
+    r_last, t_last = env2.step_many(actions, bits, fused=True)          # last step's outputs only
+    assert torch.equal(r_last.view(torch.int32), r_ref[-1].view(torch.int32)) and torch.equal(t_last, t_ref[-1])
+    assert torch.equal(env2.state, rec.state)

@@ -66,6 +66,26 @@ def main():
     t = timed(lambda: env._lib.qttt_encode(env.state.data_ptr(), vec.data_ptr(), mask.data_ptr(), n, s))
     out.append({"row": "encode", "boards": n, "us": t * 1e6, "boards_per_s": n / t,
                 "output_GBps": n * (720 + 36) / t / 1e9})
+    # fused replay (QTTT_FLAG_FUSED): T steps per launch, boards in registers
+    for n in (4096, 262144, 1 << 20):
+        T = 64
+        rec = VecEnv(n, seed=2, auto_reset=True)
+        actions = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+        for t_ in range(T):
+            rec.sample_actions(out=actions[t_])
+            rec.step_raw(actions[t_])
+        env = VecEnv(n, seed=2, auto_reset=True)
+        r = torch.empty((T, n), dtype=torch.float32, device="cuda")
+        tm = torch.empty((T, n), dtype=torch.bool, device="cuda")
+
+        def run(fused):
+            env.reset()
+            env.step_many(actions, reward=r, terminated=tm, fused=fused)
+        tf = timed(lambda: run(True), reps=10)
+        tu = timed(lambda: run(False), reps=10)
+        out.append({"row": "step_many_T64_every_output_kept", "boards": n, "fused_us_per_step": tf * 1e6 / T,
+                    "unfused_us_per_step": tu * 1e6 / T, "fused_steps_per_s": n * T / tf,
+                    "unfused_steps_per_s": n * T / tu})
     for o in out:
         print(json.dumps(o))
 
