@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqttt_hip.so")
+# QTTT_LIB_PATH: load another build of the same ABI (A/B diagnostics); default = the in-tree build
+LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.so")
 
 ABI_VERSION = 1
 FLAG_AUTO_RESET = 1
