@@ -405,109 +405,131 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
 }
 
 // ====================================================================== cold paths
-// Friendly unpacked form for the kernels that are not on the hot path.
+// Friendly unpacked form for the kernels that are not on the hot path.  Everything is kept in
+// packed words with shift accessors — no per-thread arrays: runtime-indexed arrays would live in
+// scratch memory, and the scratch-backed version of these kernels returned an occasional wrong
+// element under 512-thread workgroups on this part (tools/flake_probe.py).
+// tests/test_abi_and_host.py asserts that no kernel of this file uses scratch.
 struct Cold {
-    u32 n;          // n_moves
-    u32 cl;         // classical mask
+    u32 n;          // n_moves, autofill move included
+    u32 cl;         // classical mask, autofilled square included
     u32 done;
-    u32 mv[9];      // mv[t] = lo | hi<<4 of round t (valid for t < n)
-    u32 sq[9];      // nibble per square
-    u32 comps[4];   // 9-bit masks, list order
+    u64 mvq;        // moves of rounds 0..7: byte t = lo | hi<<4
+    u32 mv8;        // move of round 8
+    u64 sq;         // 9 nibbles, true values (0xF = root / isolated / empty)
+    u64 comps;      // 4 x 9-bit masks, list order
+    __device__ u32 mv(u32 t) const { return t >= 8u ? mv8 : (u32)(mvq >> (t * 8u)) & 0xFFu; }
+    __device__ void set_mv(u32 t, u32 m) {
+        if (t >= 8u) mv8 = m & 0xFFu;
+        else mvq = (mvq & ~(0xFFull << (t * 8u))) | ((u64)(m & 0xFFu) << (t * 8u));
+    }
+    __device__ u32 sqv(u32 v) const { return (u32)(sq >> (v * 4u)) & 0xFu; }
+    __device__ void set_sq(u32 v, u32 x) { sq = (sq & ~(0xFull << (v * 4u))) | ((u64)(x & 0xFu) << (v * 4u)); }
+    __device__ u32 comp(u32 k) const { return (u32)(comps >> (9u * k)) & 0x1FFu; }
 };
 
-__device__ inline void cold_unpack(u64 A, u64 B, u32 C, Cold &s) {
+__device__ __forceinline__ void cold_unpack(u64 A, u64 B, u32 C, Cold &s) {
     const u32 B1 = (u32)(B >> 32);
     s.n = (B1 >> B1_N_SHIFT) & 0xFu;
     s.cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
     s.done = B1 >> 31;
-    const u32 mv8 = (B1 >> B1_MV8_SHIFT) & 0xFFu;
-    for (u32 t = 0; t < 9; ++t) {
-        u32 m = 0;
-        if (t < s.n) {
-            const u32 q = s.n - 1u - t;                          // queue index of round t
-            m = q >= 8u ? mv8 : (u32)(A >> (q * 8u)) & 0xFFu;
-        }
-        s.mv[t] = m;
+    const u32 q8 = (B1 >> B1_MV8_SHIFT) & 0xFFu;                  // queue entry 8
+    s.mvq = 0;
+    s.mv8 = 0;
+    for (u32 t = 0; t < s.n; ++t) {
+        const u32 q = s.n - 1u - t;                              // queue index of round t
+        s.set_mv(t, q >= 8u ? q8 : (u32)(A >> ((q & 7u) * 8u)) & 0xFFu);
     }
-    for (u32 v = 0; v < 9; ++v) s.sq[v] = ((u32)(B >> (v * 4u)) & 0xFu) ^ 0xFu;   // stored complemented
-    const u64 comps = (u64)C | ((u64)((B1 >> B1_CHI_SHIFT) & 0xFu) << 32);
-    for (u32 k = 0; k < 4; ++k) s.comps[k] = (u32)(comps >> (9u * k)) & 0x1FFu;
+    s.sq = (B & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;                // stored complemented
+    s.comps = (u64)C | ((u64)((B1 >> B1_CHI_SHIFT) & 0xFu) << 32);
     // materialise the implicit autofill (board.py:22-25): exactly 8 classical squares
     if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {
         const u32 idx = (u32)__builtin_ctz(~s.cl);
-        s.sq[idx] = s.n;                                         // board[idx] = len(self.moves)
+        s.set_sq(idx, s.n);                                      // board[idx] = len(self.moves)
         s.cl |= 1u << idx;
-        s.mv[s.n] = idx | (idx << 4);                            // moves.append((idx, idx, len))
+        s.set_mv(s.n, idx | (idx << 4));                         // moves.append((idx, idx, len))
         s.n += 1u;
     }
 }
 
-__device__ inline void cold_pack(const Cold &in, u64 &A, u64 &B, u32 &C) {
+__device__ __forceinline__ void cold_pack(const Cold &in, u64 &A, u64 &B, u32 &C) {
     Cold s = in;
     // strip an explicit autofill move (lo == hi, always the last one) back to the implicit form
-    if (s.n >= 1u && s.n <= 9u && (s.mv[s.n - 1u] & 0xFu) == (s.mv[s.n - 1u] >> 4)) {
-        const u32 idx = s.mv[s.n - 1u] & 0xFu;
-        if (idx < 9u) {
-            s.cl &= ~(1u << idx);
-            s.sq[idx] = 0xFu;
+    if (s.n >= 1u && s.n <= 9u) {
+        const u32 last = s.mv(s.n - 1u);
+        if ((last & 0xFu) == (last >> 4)) {
+            const u32 idx = last & 0xFu;
+            if (idx < 9u) {
+                s.cl &= ~(1u << idx);
+                s.set_sq(idx, 0xFu);
+            }
+            s.n -= 1u;
         }
-        s.n -= 1u;
     }
     A = 0;
-    u32 mv8 = 0;
-    for (u32 t = 0; t < s.n && t < 9; ++t) {
+    u32 q8 = 0;
+    for (u32 t = 0; t < s.n && t < 9u; ++t) {
         const u32 q = s.n - 1u - t;
-        if (q >= 8u) mv8 = s.mv[t] & 0xFFu;
-        else A |= (u64)(s.mv[t] & 0xFFu) << (q * 8u);
+        if (q >= 8u) q8 = s.mv(t);
+        else A |= (u64)s.mv(t) << (q * 8u);
     }
-    u64 sq = 0;
-    for (u32 v = 0; v < 9; ++v) sq |= (u64)((s.sq[v] & 0xFu) ^ 0xFu) << (v * 4u);
-    u64 comps = 0;
-    for (u32 k = 0; k < 4; ++k) comps |= (u64)(s.comps[k] & 0x1FFu) << (9u * k);
-    const u32 B1 = (u32)(sq >> 32) | (mv8 << B1_MV8_SHIFT) | (s.n << B1_N_SHIFT) | (s.cl << B1_CL_SHIFT) |
-                   ((u32)(comps >> 32) << B1_CHI_SHIFT) | (s.done ? B1_DONE : 0u);
-    B = (u64)(u32)sq | ((u64)B1 << 32);
-    C = (u32)comps;
+    const u64 sqc = (s.sq & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;
+    const u32 B1 = (u32)(sqc >> 32) | (q8 << B1_MV8_SHIFT) | (s.n << B1_N_SHIFT) | (s.cl << B1_CL_SHIFT) |
+                   (((u32)(s.comps >> 32) & 0xFu) << B1_CHI_SHIFT) | (s.done ? B1_DONE : 0u);
+    B = (u64)(u32)sqc | ((u64)B1 << 32);
+    C = (u32)s.comps;
 }
 
-__device__ inline void cold_check_win(const Cold &s, int &p1, int &p2) {
+// one line of board.py:85-110: p1/p2 = min over completed lines of the max round in the line
+__device__ __forceinline__ void cold_line(const Cold &s, u32 X, u32 O, u32 L, int &p1, int &p2) {
+    int mx = -1;
+    for (u32 v = 0; v < 9; ++v)
+        if (L >> v & 1u) mx = max(mx, (int)s.sqv(v));
+    const bool c1 = (X & L) == L, c2 = !c1 && (O & L) == L;     // selects, not a choice of address:
+    p1 = c1 ? min(p1, mx) : p1;                                  // keeps p1/p2 in registers
+    p2 = c2 ? min(p2, mx) : p2;
+}
+
+__device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) {
     // board.py:71-115, lines in the reference's order (rows, cols, 2-4-6, 0-4-8)
-    const u32 lines[8] = {0x007u, 0x038u, 0x1C0u, 0x049u, 0x092u, 0x124u, 0x054u, 0x111u};
     u32 X = 0, O = 0;
     for (u32 v = 0; v < 9; ++v)
-        if (s.cl >> v & 1u) { if (s.sq[v] & 1u) O |= 1u << v; else X |= 1u << v; }
+        if (s.cl >> v & 1u) { if (s.sqv(v) & 1u) O |= 1u << v; else X |= 1u << v; }
     p1 = 10;
     p2 = 10;
-    for (int l = 0; l < 8; ++l) {
-        const u32 L = lines[l];
-        int mx = -1;
-        for (u32 v = 0; v < 9; ++v)
-            if (L >> v & 1u) mx = max(mx, (int)s.sq[v]);
-        if ((X & L) == L) p1 = min(p1, mx);
-        else if ((O & L) == L) p2 = min(p2, mx);
-    }
+    cold_line(s, X, O, 0x007u, p1, p2);
+    cold_line(s, X, O, 0x038u, p1, p2);
+    cold_line(s, X, O, 0x1C0u, p1, p2);
+    cold_line(s, X, O, 0x049u, p1, p2);
+    cold_line(s, X, O, 0x092u, p1, p2);
+    cold_line(s, X, O, 0x124u, p1, p2);
+    cold_line(s, X, O, 0x054u, p1, p2);
+    cold_line(s, X, O, 0x111u, p1, p2);
     if (p1 >= 10) p1 = -1;
     if (p2 >= 10) p2 = -1;
 }
 
-__global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(
+#define QTTT_COLD_BLOCK 256
+
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, int8_t *classical, uint8_t *q_p1,
     uint8_t *q_p1_len, uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
     cold_unpack(pA[i], pB[i], pC[i], s);
     for (u32 v = 0; v < 9; ++v)                                   // env.py:71,82
-        classical[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sq[v] : (int8_t)-1;
+        classical[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sqv(v) : (int8_t)-1;
     u32 n1 = 0, n2 = 0;
-    for (u32 t = 0; t < 9; ++t) {                                 // env.py:72-77
-        const u32 lo = s.mv[t] & 0xFu, hi = s.mv[t] >> 4;
-        const bool live = t < s.n && !(s.cl >> lo & 1u);          // round t is not on the board
-        if (live && (t & 1u)) {
+    for (u32 t = 0; t < s.n; ++t) {                               // env.py:72-77
+        const u32 m = s.mv(t);
+        const u32 lo = m & 0xFu, hi = m >> 4;
+        if (s.cl >> lo & 1u) continue;                            // round t is on the board
+        if (t & 1u) {
             q_p2[i * 8 + n2 * 2] = (uint8_t)lo;
             q_p2[i * 8 + n2 * 2 + 1] = (uint8_t)hi;
             ++n2;
-        } else if (live) {
+        } else {
             q_p1[i * 10 + n1 * 2] = (uint8_t)lo;
             q_p1[i * 10 + n1 * 2 + 1] = (uint8_t)hi;
             ++n1;
@@ -520,9 +542,9 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(
     turn[i] = (uint8_t)(s.n & 1u);                                // env.py:83
 }
 
-__global__ __launch_bounds__(QTTT_BLOCK) void check_win_kernel(
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, int8_t *p1_round, int8_t *p2_round, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
     cold_unpack(pA[i], pB[i], pC[i], s);
@@ -532,62 +554,67 @@ __global__ __launch_bounds__(QTTT_BLOCK) void check_win_kernel(
     p2_round[i] = (int8_t)p2;
 }
 
-__global__ __launch_bounds__(QTTT_BLOCK) void export_kernel(
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, uint8_t *moves, uint8_t *n_moves,
     int8_t *board, uint16_t *qmask, uint8_t *n_q, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
     cold_unpack(pA[i], pB[i], pC[i], s);
     for (u32 t = 0; t < 9; ++t) {
         const bool used = t < s.n;
-        moves[i * 18 + t * 2] = used ? (uint8_t)(s.mv[t] & 0xFu) : (uint8_t)255;
-        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)(s.mv[t] >> 4) : (uint8_t)255;
+        const u32 m = s.mv(t);
+        moves[i * 18 + t * 2] = used ? (uint8_t)(m & 0xFu) : (uint8_t)255;
+        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)(m >> 4) : (uint8_t)255;
     }
     n_moves[i] = (uint8_t)s.n;
     for (u32 v = 0; v < 9; ++v)
-        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sq[v] : (int8_t)-1;
+        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sqv(v) : (int8_t)-1;
     u32 nq = 0;
     for (u32 k = 0; k < 4; ++k) {
-        qmask[i * 4 + k] = (uint16_t)s.comps[k];
-        nq += s.comps[k] != 0u;
+        qmask[i * 4 + k] = (uint16_t)s.comp(k);
+        nq += s.comp(k) != 0u;
     }
     n_q[i] = (uint8_t)nq;
 }
 
 // Builds the packed state (incl. the rooted forest) from Board attributes assigned by a caller
 // (mcts.py:11-17,241 assign .board/.moves/.qstructs directly).  Not a hot path.
-__global__ __launch_bounds__(QTTT_BLOCK) void import_kernel(
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
     u64 *pA, u64 *pB, u32 *pC, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
     const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
     s.n = min((u32)n_moves[i], 9u);
     s.cl = 0;
-    for (u32 t = 0; t < 9; ++t)
-        s.mv[t] = t < s.n ? ((u32)(moves[i * 18 + t * 2] & 0xFu) | ((u32)(moves[i * 18 + t * 2 + 1] & 0xFu) << 4)) : 0u;
+    s.mvq = 0;
+    s.mv8 = 0;
+    for (u32 t = 0; t < s.n; ++t)
+        s.set_mv(t, (u32)(moves[i * 18 + t * 2] & 0xFu) | ((u32)(moves[i * 18 + t * 2 + 1] & 0xFu) << 4));
+    s.sq = 0xFFFFFFFFFull;
     for (u32 v = 0; v < 9; ++v) {
         const int bv = board[i * 9 + v];
-        s.sq[v] = 0xFu;
         if (bv >= 0) {
             s.cl |= 1u << v;
-            s.sq[v] = (u32)bv & 0xFu;
+            s.set_sq(v, (u32)bv & 0xFu);
         }
     }
     const u32 nq = min((u32)n_q[i], 4u);
-    for (u32 k = 0; k < 4; ++k) s.comps[k] = k < nq ? (qmask[i * 4 + k] & 0x1FFu) : 0u;
+    s.comps = 0;
+    for (u32 k = 0; k < nq; ++k) s.comps |= (u64)(qmask[i * 4 + k] & 0x1FFu) << (9u * k);
     // root every tree of live edges: grow from the lowest square of each tree
     u32 rooted = 0;
     for (int pass = 0; pass < 9; ++pass) {
         bool grew = false;
         u32 cand = 0;
         for (u32 t = 0; t < s.n; ++t) {
-            const u32 lo = s.mv[t] & 0xFu, hi = s.mv[t] >> 4;
+            const u32 m = s.mv(t);
+            const u32 lo = m & 0xFu, hi = m >> 4;
             if (lo == hi || lo > 8u || hi > 8u || (s.cl >> lo & 1u) || (s.cl >> hi & 1u)) continue;
             const bool rl = rooted >> lo & 1u, rh = rooted >> hi & 1u;
-            if (rl && !rh) { s.sq[hi] = t; rooted |= 1u << hi; grew = true; }
-            else if (rh && !rl) { s.sq[lo] = t; rooted |= 1u << lo; grew = true; }
+            if (rl && !rh) { s.set_sq(hi, t); rooted |= 1u << hi; grew = true; }
+            else if (rh && !rl) { s.set_sq(lo, t); rooted |= 1u << lo; grew = true; }
             cand |= (1u << lo) | (1u << hi);
         }
         if (!grew) {
@@ -680,7 +707,7 @@ struct PairLut {
 __constant__ PairLut g_pair_lut = PairLut();
 
 // GameState.actions (mcts.py:20-27): action a is listed iff both its squares are classical-empty
-__device__ inline u64 cold_legal_mask(const Cold &s) {
+__device__ __forceinline__ u64 cold_legal_mask(const Cold &s) {
     u64 m = 0;
     for (int a = 0; a < 36; ++a) {
         const u32 pr = g_pair_lut.b[a];
@@ -690,7 +717,7 @@ __device__ inline u64 cold_legal_mask(const Cold &s) {
 }
 
 // GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal
-__device__ inline void cold_update_winner(const Cold &s, int &winner, int &terminal) {
+__device__ __forceinline__ void cold_update_winner(const Cold &s, int &winner, int &terminal) {
     int p1, p2;
     cold_check_win(s, p1, p2);
     winner = -1;
@@ -712,14 +739,14 @@ __device__ inline u64 py_tuple_fin(u64 acc, u64 len) {
     acc += len ^ (2870177450012600261ull ^ 3527539ull);
     return acc == ~0ull ? 1546275796ull : acc;
 }
-__device__ inline int64_t cold_py_hash(const Cold &s) {
+__device__ __forceinline__ int64_t cold_py_hash(const Cold &s) {
     u64 acc = 2870177450012600261ull;
     for (u32 v = 0; v < 9; ++v)
-        acc = py_tuple_acc(acc, (s.cl >> v & 1u) ? (u64)s.sq[v] : (u64)(int64_t)-2);
+        acc = py_tuple_acc(acc, (s.cl >> v & 1u) ? (u64)s.sqv(v) : (u64)(int64_t)-2);
     for (u32 t = 0; t < s.n; ++t) {
         u64 in = 2870177450012600261ull;
-        in = py_tuple_acc(in, (u64)(s.mv[t] & 0xFu));
-        in = py_tuple_acc(in, (u64)(s.mv[t] >> 4));
+        in = py_tuple_acc(in, (u64)(s.mv(t) & 0xFu));
+        in = py_tuple_acc(in, (u64)(s.mv(t) >> 4));
         in = py_tuple_acc(in, (u64)t);
         acc = py_tuple_acc(acc, py_tuple_fin(in, 3));
     }
@@ -843,12 +870,12 @@ __global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
         cold_unpack(pA[i], pB[i], pC[i], s);
         float *o = tile + threadIdx.x * 180;
         u32 qsets = 0;
-        for (u32 k = 0; k < 4; ++k) qsets |= s.comps[k];
+        for (u32 k = 0; k < 4; ++k) qsets |= s.comp(k);
         for (u32 v = 0; v < 9; ++v) {
-            const u32 col = (s.cl >> v & 1u) ? s.sq[v] : 9u;        // board -1 indexes column 9
+            const u32 col = (s.cl >> v & 1u) ? s.sqv(v) : 9u;        // board -1 indexes column 9
             u32 touched = 0;                                       // rounds whose move touches v
             for (u32 t = 0; t < s.n; ++t)
-                if ((s.mv[t] & 0xFu) == v || (s.mv[t] >> 4) == v) touched |= 1u << t;
+                if ((s.mv(t) & 0xFu) == v || (s.mv(t) >> 4) == v) touched |= 1u << t;
             for (u32 c = 0; c < 10; ++c) {
                 o[v * 10 + c] = c == col ? 1.0f : 0.0f;
                 float q = (touched >> c & 1u) ? (1.0f / 3.0f) : 0.0f;   // 1/math.sqrt(9)
@@ -888,6 +915,7 @@ inline int &tuning_bpl() {
 }
 
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
+inline int cold_grid_for(int64_t n) { return (int)((n + QTTT_COLD_BLOCK - 1) / QTTT_COLD_BLOCK); }
 inline int step_grid_for(int64_t n_groups) {
     return (int)((n_groups + (int64_t)QTTT_BLOCK * QTTT_TPL - 1) / ((int64_t)QTTT_BLOCK * QTTT_TPL));
 }
@@ -1034,7 +1062,7 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     if (n == 0) return 0;
     if (!state || !classical || !q_p1 || !q_p1_len || !q_p2 || !q_p2_len || !turn) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(observe_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(observe_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.A, p.B, p.C, classical, q_p1, q_p1_len, q_p2, q_p2_len, turn, n);
     return launch_status();
 }
@@ -1044,7 +1072,7 @@ int qttt_check_win(const void *state, int8_t *p1_round, int8_t *p2_round, int64_
     if (n == 0) return 0;
     if (!state || !p1_round || !p2_round) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(check_win_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(check_win_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.A, p.B, p.C, p1_round, p2_round, n);
     return launch_status();
 }
@@ -1055,7 +1083,7 @@ int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *boa
     if (n == 0) return 0;
     if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(export_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(export_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.A, p.B, p.C, moves, n_moves, board, qmask, n_q, n);
     return launch_status();
 }
@@ -1066,7 +1094,7 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
     if (n == 0) return 0;
     if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
     Planes p = planes(state, n);
-    hipLaunchKernelGGL(import_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(import_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.A, p.B, p.C, moves, n_moves, board, qmask, n_q, n);
     return launch_status();
 }

@@ -87,3 +87,20 @@ def test_oracle_ind2move_table():
     import oracle
     pairs = [oracle.ind2move(a) for a in range(36)]
     assert pairs == [(i, j) for i in range(9) for j in range(i + 1, 9)]
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Every kernel keeps its working set in registers / LDS: private (scratch) memory is both slow
+    and the one thing that ever produced a wrong element here (runtime-indexed per-thread arrays
+    under 512-thread workgroups, tools/flake_probe.py).  Checked from the compiler's own report."""
+    import subprocess
+    src = os.path.join(ROOT, "qtttgym_amd", "csrc", "qttt_kernels.hip")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
+                          "-I" + os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage",
+                          "-o", os.devnull, src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) and len(names) >= 25
+    assert all(v == 0 for v in scratch), [n for n, v in zip(names, scratch) if v]

@@ -28,7 +28,11 @@ def main():
             checks = [("board", ex["board"], g["board"][:, t]), ("n_moves", ex["n_moves"], g["n_moves"][:, t]),
                       ("moves", ex["moves"], g["moves"][:, t]),
                       ("reward", reward.cpu().numpy().view(np.uint32), g["reward"][:, t].astype(np.float32).view(np.uint32)),
-                      ("terminated", term.cpu().numpy().astype(np.uint8), g["terminated"][:, t])]
+                      ("terminated", term.cpu().numpy().astype(np.uint8), g["terminated"][:, t]),
+                      ("obs.classical", obs["classical"].cpu().numpy(), g["board"][:, t]),
+                      ("obs.q_p1", obs["q_states_p1"].cpu().numpy(), g["q_p1"][:, t]),
+                      ("obs.q_p2", obs["q_states_p2"].cpu().numpy(), g["q_p2"][:, t]),
+                      ("obs.turn", obs["turn"].cpu().numpy(), g["turn"][:, t])]
             for name, got, want in checks:
                 if not np.array_equal(got, want):
                     idx = np.argwhere(got != want)
