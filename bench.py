@@ -68,9 +68,33 @@ def cpu_baseline(actions_host, seed, budget_s=12.0):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
+    py = python_interpreter_line(actions_host, seed)
     return {"value": total / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "python_interpreter_steps_per_s": py,
             "sample": "%d boards x %d recorded steps of the same workload (uniform-legal policy, "
                       "auto-reset), %d threads x %d boards, %.1f s" % (per * cores, total // (per * cores), cores, per, dt)}
+
+
+def python_interpreter_line(actions_host, seed, budget_s=2.0):
+    """The like-for-like interpreter-speed line: oracle/py_env.py, a pure-Python
+    single-board restatement with the reference's own data structures, one core, ~2 s."""
+    import oracle
+    from oracle.py_env import PyEnv
+    T = actions_host.shape[0]
+    n_boards = actions_host.shape[1]
+    done, b = 0, 0
+    t_end = time.perf_counter() + budget_s
+    t0 = time.perf_counter()
+    while time.perf_counter() < t_end:
+        env = PyEnv()
+        for t in range(min(T, 64)):
+            a0, a1 = int(actions_host[t, b, 0]), int(actions_host[t, b, 1])
+            _, term = env.step(a0, a1, oracle.collapse_bit(seed, b, t))
+            done += 1
+            if term:
+                env.reset()          # auto-reset, like the workload
+        b = (b + 1) % n_boards
+    return done / (time.perf_counter() - t0)
 
 
 def main():

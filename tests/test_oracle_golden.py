@@ -99,3 +99,16 @@ def test_oracle_state_invariants_under_random_play():
                 lo, hi = int(ob.b["moves"][i][j][0]), int(ob.b["moves"][i][j][1])
                 if lo == hi:
                     assert j == 8 and int(board[i][lo]) == 8       # autofill is always round 8
+
+
+def test_pure_python_restatement_matches_golden(golden):
+    from oracle.py_env import PyEnv
+    acts, bits = golden["actions"], golden["bits"]
+    for e in range(0, acts.shape[0], 3):
+        env = PyEnv()
+        for t in range(acts.shape[1]):
+            r, term = env.step(int(acts[e, t, 0]), int(acts[e, t, 1]), int(bits[e, t]))
+            assert env.b.board == golden["board"][e, t].tolist()
+            assert len(env.b.moves) == int(golden["n_moves"][e, t])
+            assert np.float64(r).view(np.uint64) == golden["reward"][e, t].view(np.uint64)
+            assert term == bool(golden["terminated"][e, t])
