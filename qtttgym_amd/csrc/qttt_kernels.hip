@@ -215,7 +215,9 @@ __device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32
             const u64 XB = ((A ^ (A >> 4)) & 0x0F0F0F0F0F0F0F0Full) << 2;
             const u32 XB0 = (u32)XB, XB1 = (u32)(XB >> 32);
             const u32 base = 0x0C0C0BF0u + n;
-            u32 v4 = x4, prev = 0u;
+            // x itself receives this move as its parent edge (complemented round n), every later
+            // node on the path receives the edge its child used to have
+            u32 v4 = x4, prev = 0xFu ^ n;
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const u32 ec = (u32)(B >> v4) & 0xFu;
@@ -225,7 +227,6 @@ __device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32
                 prev = ec;
             }
         }
-        B |= (u64)(0xFu ^ n) << x4;                      // sq[x]: root -> parent edge = this move
         B0 = (u32)B;
         B1 = (u32)(B >> 32);
         // board.py:19: append to the queue (the byte pushed out of A is 0 unless this is entry 9)
