@@ -855,24 +855,26 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
 }
 
 // GameState.to_vector (mcts.py:67-85) as f32[18][10] and action_mask (mcts.py:87-91).
-// One wave per 64 boards: each lane builds its board's 180 floats in LDS, then the wave streams
-// the tile out as 45 fully coalesced 1-KiB stores (a lane-per-board store would scatter 16-byte
-// pieces 720 bytes apart).
-#define QTTT_ENC_BLOCK 64
+// A 256-thread workgroup owns 64 boards: thread (board b, part p) builds the rows of squares
+// p, p+4, p+8 in an LDS tile, then all four waves stream the tile out as fully coalesced 16-byte
+// stores (a lane-per-board store would scatter 16-byte pieces 720 bytes apart; one wave per tile
+// would leave the CU at 3 waves because of the 46 KB tile).
+#define QTTT_ENC_BOARDS 64
+#define QTTT_ENC_BLOCK 256
 __global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, float *vec, uint8_t *mask, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float tile[QTTT_ENC_BLOCK * 180];
-    __shared__ __attribute__((aligned(16))) uint8_t mtile[QTTT_ENC_BLOCK * 36];
-    const int64_t base = (int64_t)blockIdx.x * QTTT_ENC_BLOCK;
-    const int64_t i = base + threadIdx.x;
-    const u32 valid = (u32)min((int64_t)QTTT_ENC_BLOCK, n - base);
-    if (threadIdx.x < valid) {
+    __shared__ __attribute__((aligned(16))) float tile[QTTT_ENC_BOARDS * 180];
+    __shared__ __attribute__((aligned(16))) uint8_t mtile[QTTT_ENC_BOARDS * 36];
+    const int64_t base = (int64_t)blockIdx.x * QTTT_ENC_BOARDS;
+    const u32 b = threadIdx.x & 63u, part = threadIdx.x >> 6;
+    const int64_t i = base + b;
+    const u32 valid = (u32)min((int64_t)QTTT_ENC_BOARDS, n - base);
+    if (b < valid) {
         Cold s;
         cold_unpack(pA[i], pB[i], pC[i], s);
-        float *o = tile + threadIdx.x * 180;
-        u32 qsets = 0;
-        for (u32 k = 0; k < 4; ++k) qsets |= s.comp(k);
-        for (u32 v = 0; v < 9; ++v) {
+        float *o = tile + b * 180;
+        const u32 qsets = s.comp(0) | s.comp(1) | s.comp(2) | s.comp(3);
+        for (u32 v = part; v < 9; v += 4) {
             const u32 col = (s.cl >> v & 1u) ? s.sqv(v) : 9u;        // board -1 indexes column 9
             u32 touched = 0;                                       // rounds whose move touches v
             for (u32 t = 0; t < s.n; ++t)
@@ -884,17 +886,17 @@ __global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
                 o[90 + v * 10 + c] = q;
             }
         }
-        if (mask) {
+        if (mask && part == 3u) {                                  // the lightest part also does the mask
             const u64 lm = cold_legal_mask(s);
-            for (int a = 0; a < 36; ++a) mtile[threadIdx.x * 36 + a] = (uint8_t)(lm >> a & 1ull);
+            for (int a = 0; a < 36; ++a) mtile[b * 36 + a] = (uint8_t)(lm >> a & 1ull);
         }
     }
     __syncthreads();
     {
         const u32 n4 = valid * 45u;                                // float4 pieces in this tile
-        const float4 *src = reinterpret_cast<const float4 *>(tile);
-        float4 *dst = reinterpret_cast<float4 *>(vec + base * 180);
-        for (u32 k = threadIdx.x; k < n4; k += QTTT_ENC_BLOCK) dst[k] = src[k];
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(tile);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(vec + base * 180);
+        for (u32 k = threadIdx.x; k < n4; k += QTTT_ENC_BLOCK) __builtin_nontemporal_store(src[k], &dst[k]);
     }
     if (mask) {
         const u32 n4 = valid * 9u;                                 // 4-byte pieces (36 = 9 x 4)
@@ -1158,7 +1160,7 @@ int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *s
     if (!state || !vec) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
     if (((uintptr_t)vec & 15u) || ((uintptr_t)mask & 3u)) return QTTT_ERR_ACTION;   // vector stores
-    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + QTTT_ENC_BLOCK - 1) / QTTT_ENC_BLOCK)),
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + QTTT_ENC_BOARDS - 1) / QTTT_ENC_BOARDS)),
                        dim3(QTTT_ENC_BLOCK), 0, (hipStream_t)stream, p.A, p.B, p.C, vec, mask, n);
     return launch_status();
 }
