@@ -68,6 +68,28 @@ __global__ __launch_bounds__(256) void floor_kernel(u64 *pA, u64 *pB, u32 *pC, c
     st_nt(reinterpret_cast<Vec<uint8_t, BPL> *>(term + i0), tm);
 }
 
+// the same with a 16-byte state (planes A and B only): what a 39 B/step layout would reach
+template <int BPL>
+__global__ __launch_bounds__(256) void floor16_kernel(u64 *pA, u64 *pB, const uint16_t *actions,
+                                                      u32 *reward, uint8_t *term, int64_t n_groups) {
+    int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_groups) return;
+    int64_t i0 = j * BPL;
+    Vec<u64, BPL> a = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pA + i0));
+    Vec<u64, BPL> b = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pB + i0));
+    Vec<uint16_t, BPL> act = ld_nt(reinterpret_cast<const Vec<uint16_t, BPL> *>(actions + i0));
+    Vec<u32, BPL> rw; Vec<uint8_t, BPL> tm;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        a.v[k] ^= act.v[k]; b.v[k] += 1;
+        rw.v[k] = (u32)a.v[k]; tm.v[k] = (uint8_t)b.v[k];
+    }
+    st_nt(reinterpret_cast<Vec<u64, BPL> *>(pA + i0), a);
+    st_nt(reinterpret_cast<Vec<u64, BPL> *>(pB + i0), b);
+    st_nt(reinterpret_cast<Vec<u32, BPL> *>(reward + i0), rw);
+    st_nt(reinterpret_cast<Vec<uint8_t, BPL> *>(term + i0), tm);
+}
+
 struct Lib {
     std::string spec, path;
     int bpl, pipe;
@@ -116,7 +138,7 @@ int main(int argc, char **argv) {
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     u64 *pA = (u64 *)state; int64_t stride = (n + 63) & ~63ll; u64 *pB = pA + stride; u32 *pC = (u32 *)(pB + stride);
-    std::vector<float> fl[3];
+    std::vector<float> fl[3], fl16;
     for (int r = 0; r < reps; ++r) {
         for (auto &L : libs) {
             L.set_tuning(L.bpl, L.pipe);
@@ -144,6 +166,18 @@ int main(int argc, char **argv) {
             CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             fl[vi++].push_back(ms * 1e3f / K);
+        }
+        {
+            CK(hipEventRecord(e0, s));
+            for (int t = 0; t < K; ++t) {
+                const uint16_t *a16 = (const uint16_t *)(actions + (size_t)(W + t) * 2 * n);
+                int64_t ng = n / 2; dim3 g((unsigned)((ng + 255) / 256)), b(256);
+                hipLaunchKernelGGL(floor16_kernel<2>, g, b, 0, s, pA, pB, a16, (u32 *)reward, term, ng);
+            }
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            fl16.push_back(ms * 1e3f / K);
         }
     }
     // optional: per-wave timeline of one launch from a -DQTTT_DEBUG_STAMPS build (last lib)
@@ -198,5 +232,8 @@ int main(int argc, char **argv) {
                fl[vi][fl[vi].size() / 2], "", bytes / fl[vi].front() * 1e-3);
         ++vi;
     }
+    std::sort(fl16.begin(), fl16.end());
+    printf("floor 16-byte state, bpl=2 %23s us/launch min %6.2f med %6.2f  %19s %5.0f GB/s (39 B/step)\n", "",
+           fl16.front(), fl16[fl16.size() / 2], "", 39.0 * n / fl16.front() * 1e-3);
     return 0;
 }
