@@ -105,9 +105,10 @@ def main():
     ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["replay", "policy"], default="replay",
+    ap.add_argument("--mode", choices=["replay", "policy", "random"], default="replay",
                     help="replay: timed region is env.step only (default, the metric); "
-                         "policy: policy kernel + env.step per step")
+                         "policy: policy kernel + env.step per step; "
+                         "random: policy and env.step fused in one kernel per step")
     args = ap.parse_args()
 
     import torch
@@ -157,11 +158,17 @@ def main():
 
     # ---- timed: replay --------------------------------------------------------------
     env.reset()
+    def one_step():
+        if args.mode == "policy":
+            env.step_raw(env.sample_actions())
+        else:
+            env.step_random()
+
     if args.mode == "replay":
         env.step_many(actions[:W])
     else:
         for t in range(W):
-            env.step_raw(env.sample_actions())
+            one_step()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     barrier()
@@ -172,7 +179,7 @@ def main():
         env.step_many(actions[W:])
     else:
         for t in range(K):
-            env.step_raw(env.sample_actions())
+            one_step()
     ev1.record()
     torch.cuda.synchronize(dev)
     barrier()
@@ -201,7 +208,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%d boards per GPU, uniform-legal random policy, auto-reset, "
                                    "%s" % (B, "recorded actions replayed (env.step only in the timed region)"
-                                           if args.mode == "replay" else "policy kernel + env.step per step"),
+                                           if args.mode == "replay" else ("policy kernel + env.step per step" if args.mode == "policy"
+                                                                    else "policy + env.step fused in one kernel per step")),
                        "boards_per_gpu": B, "state_bytes_per_board": STATE_BYTES,
                        "parallelism": "shard%d" % world, "mode": args.mode,
                        "replay_matches_recording": replay_ok,

@@ -138,6 +138,13 @@ int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *s
  * Process-wide; also settable through QTTT_STEP_BPL before the first call.  `reserved` = 0. */
 int qttt_set_tuning(int boards_per_lane, int reserved);
 
+/* One step of every board under that policy with policy and step in ONE kernel: exactly
+ * qttt_sample_actions followed by qttt_step(bits = NULL) with the same seed / step_idx /
+ * board_offset / flags.  actions_out u8[n,2] receives the actions played (nullable). */
+int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                     uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
+                     int64_t n, void *stream);
+
 /* The counter hash itself (host-callable, no device work), so callers can reproduce bits. */
 uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx);
 

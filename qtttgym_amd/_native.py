@@ -30,6 +30,7 @@ SIGNATURES = {
     "qttt_rollout": (_i32, [_vp, _u64, _u32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "qttt_encode": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_set_tuning": (_i32, [_i32, _i32]),
+    "qttt_step_random": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _vp]),
     "qttt_hash": (_u64, [_u64, _u64, _u32]),
 }
 

@@ -175,6 +175,46 @@ __device__ inline u32 collapse_bit_of(u32 x) {
     return x >> 31;
 }
 
+// ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
+// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4;
+// nth_bit[m][r]: index of the r-th set bit of the 9-bit mask m.  The k-th legal action of a board
+// with empty-square mask m is (nth_bit[m][i], nth_bit[m][j]).
+struct PolicyLut {
+    uint8_t rank_pair[10 * 36];
+    uint8_t nth_bit[512 * 9];
+    uint8_t pad[4];
+    constexpr PolicyLut() : rank_pair(), nth_bit(), pad() {
+        for (int e = 0; e < 10; ++e) {
+            int k = 0;
+            for (int i = 0; i < e; ++i)
+                for (int j = i + 1; j < e; ++j) rank_pair[e * 36 + k++] = (uint8_t)(i | (j << 4));
+            for (; k < 36; ++k) rank_pair[e * 36 + k] = 0;
+        }
+        for (int m = 0; m < 512; ++m) {
+            int r = 0;
+            for (int v = 0; v < 9; ++v)
+                if (m >> v & 1) nth_bit[m * 9 + r++] = (uint8_t)v;
+            for (; r < 9; ++r) nth_bit[m * 9 + r] = 0;
+        }
+    }
+};
+__constant__ PolicyLut g_policy_lut = PolicyLut();
+constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 512 * 9 + 4) / 4;
+
+__device__ inline void fill_policy_lut(uint8_t *dst) {
+    const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
+    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += QTTT_BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
+}
+
+// the policy's action for a board whose empty-square mask is `empty`, from hash word h2: lo | hi<<8
+__device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32 h2) {
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 k = __umulhi(h2, (e * (e - 1u)) >> 1);
+    const u32 ij = plut[e * 36u + k];
+    const uint8_t *nth = plut + 360u + empty * 9u;
+    return (u32)nth[ij & 0xFu] | ((u32)nth[ij >> 4] << 8);
+}
+
 // ====================================================================== the hot path
 // One Env.step (env.py:34-53) on the board held in (A0,A1,B0,B1,C).  `lut` is the LDS copy of
 // g_line_lut.  Returns 0x7F iff a completed line exists afterwards (else 0); B1's done bit is
@@ -275,13 +315,16 @@ __device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32
 // BPL boards per lane: lane j owns boards [j*BPL, (j+1)*BPL), so every plane is read and written
 // with 16-byte vector accesses that are contiguous across the wave.  Addresses are a block-uniform
 // 64-bit base (scalar unit) plus a 32-bit lane offset.
-template <int BPL, bool HAS_BITS, bool AUTO_RESET>
+// SAMPLE: the action is not read but drawn in the kernel from the uniform-legal policy (and written to
+// `actions` when that is not null) — qttt_sample_actions + qttt_step in one launch.
+template <int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false>
 __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
-    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold,
+    uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi,
     u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
     int64_t i_begin, int64_t n_groups) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[512];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -314,11 +357,12 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
         b[q] = reinterpret_cast<const V64 *>(pB + ib)[g[q]];
         c[q] = reinterpret_cast<const V32 *>(pC + ib)[g[q]];
 #endif
-        act[q] = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g[q]]);
+        if (!SAMPLE) act[q] = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g[q]]);
         if (HAS_BITS) bt[q] = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g[q]]);
     }
     for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
         reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
+    if (SAMPLE) fill_policy_lut(plut);
     __syncthreads();
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -335,10 +379,22 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
             u32 A0 = (u32)a[q].v[k], A1 = (u32)(a[q].v[k] >> 32);
             u32 B0 = (u32)b[q].v[k], B1 = (u32)(b[q].v[k] >> 32);
             u32 C = c[q].v[k];
-            u32 bit;
-            if (HAS_BITS) bit = bt[q].v[k] & 1u;
-            else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
-            const u32 win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, act[q].v[k], bit, lut);
+            u32 bit, av;
+            if (SAMPLE) {
+                // the policy sees the board the step will act on: a finished board counts as empty
+                const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
+                const u32 h2 = lowbias32(h1 ^ key_hi);
+                const u32 cl = (AUTO_RESET && (B1 >> 31)) ? 0u : (B1 >> B1_CL_SHIFT) & 0x1FFu;
+                const u32 empty = ~cl & 0x1FFu;
+                av = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
+                act[q].v[k] = (uint16_t)av;
+                bit = h1 >> 31;
+            } else {
+                av = act[q].v[k];
+                if (HAS_BITS) bit = bt[q].v[k] & 1u;
+                else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+            }
+            const u32 win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, av, bit, lut);
             a[q].v[k] = (u64)A0 | ((u64)A1 << 32);
             b[q].v[k] = (u64)B0 | ((u64)B1 << 32);
             c[q].v[k] = C;
@@ -354,6 +410,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
         reinterpret_cast<V64 *>(pB + ib)[g[q]] = b[q];
         reinterpret_cast<V32 *>(pC + ib)[g[q]] = c[q];
 #endif
+        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g[q]], act[q]);
         store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g[q]], rw);
         store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g[q]], tm);
     }
@@ -633,46 +690,6 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
     pA[i] = A;
     pB[i] = B;
     pC[i] = C;
-}
-
-// ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
-// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4;
-// nth_bit[m][r]: index of the r-th set bit of the 9-bit mask m.  The k-th legal action of a board
-// with empty-square mask m is (nth_bit[m][i], nth_bit[m][j]).
-struct PolicyLut {
-    uint8_t rank_pair[10 * 36];
-    uint8_t nth_bit[512 * 9];
-    uint8_t pad[4];
-    constexpr PolicyLut() : rank_pair(), nth_bit(), pad() {
-        for (int e = 0; e < 10; ++e) {
-            int k = 0;
-            for (int i = 0; i < e; ++i)
-                for (int j = i + 1; j < e; ++j) rank_pair[e * 36 + k++] = (uint8_t)(i | (j << 4));
-            for (; k < 36; ++k) rank_pair[e * 36 + k] = 0;
-        }
-        for (int m = 0; m < 512; ++m) {
-            int r = 0;
-            for (int v = 0; v < 9; ++v)
-                if (m >> v & 1) nth_bit[m * 9 + r++] = (uint8_t)v;
-            for (; r < 9; ++r) nth_bit[m * 9 + r] = 0;
-        }
-    }
-};
-__constant__ PolicyLut g_policy_lut = PolicyLut();
-constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 512 * 9 + 4) / 4;
-
-__device__ inline void fill_policy_lut(uint8_t *dst) {
-    const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
-    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += QTTT_BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
-}
-
-// the policy's action for a board whose empty-square mask is `empty`, from hash word h2: lo | hi<<8
-__device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32 h2) {
-    const u32 e = (u32)__builtin_popcount(empty);
-    const u32 k = __umulhi(h2, (e * (e - 1u)) >> 1);
-    const u32 ij = plut[e * 36u + k];
-    const uint8_t *nth = plut + 360u + empty * 9u;
-    return (u32)nth[ij & 0xFu] | ((u32)nth[ij >> 4] << 8);
 }
 
 // legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
@@ -967,17 +984,18 @@ int qttt_reset(void *state, int64_t n, void *stream) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
-              uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
-              uint8_t *terminated, int64_t n, void *stream) {
+static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                       uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+                       uint8_t *terminated, int64_t n, void *stream, bool sample) {
     if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
-    if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
-    if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are read as u16 pairs
+    if (!state || !reward || !terminated || (!sample && !actions)) return QTTT_ERR_NULL;
+    if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are accessed as u16 pairs
     Planes p = planes(state, n);
-    const u32 key_lo = (u32)launch_key(seed, step_idx);
+    const u64 key = launch_key(seed, step_idx);
+    const u32 key_lo = (u32)key, key_hi = (u32)(key >> 32);
     hipStream_t s = (hipStream_t)stream;
-    const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
+    uint16_t *a16 = reinterpret_cast<uint16_t *>(actions);
     u32 *rb = reinterpret_cast<u32 *>(reward);
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
     // widest boards-per-lane the caller's pointers are aligned for (the planes always are)
@@ -987,14 +1005,15 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
                ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
     };
     while (bpl_max > 1 && !aligned(bpl_max)) bpl_max >>= 1;
-#define QTTT_LAUNCH(BPL, HB, AR, I0, NG, KF, IDB)                                               \
-    hipLaunchKernelGGL((step_kernel<BPL, HB, AR>), dim3(step_grid_for(NG)), dim3(QTTT_BLOCK), 0, s,  \
-                       p.A, p.B, p.C, a16, bits, (u32)(KF), (u32)(IDB), rb, terminated,         \
+#define QTTT_LAUNCH(BPL, HB, AR, SM, I0, NG, KF, IDB)                                                 \
+    hipLaunchKernelGGL((step_kernel<BPL, HB, AR, SM>), dim3(step_grid_for(NG)), dim3(QTTT_BLOCK), 0, s, \
+                       p.A, p.B, p.C, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated,        \
                        (int64_t)(I0), (int64_t)(NG))
-#define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                          \
-    do {                                                             \
-        if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, I0, NG, KF, IDB); } \
-        else      { if (ar) QTTT_LAUNCH(BPL, false, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, I0, NG, KF, IDB); } \
+#define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                                                           \
+    do {                                                                                              \
+        if (sample) { if (ar) QTTT_LAUNCH(BPL, false, true, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, true, I0, NG, KF, IDB); } \
+        else if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, false, I0, NG, KF, IDB); } \
+        else { if (ar) QTTT_LAUNCH(BPL, false, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, false, I0, NG, KF, IDB); } \
     } while (0)
     // The hash folds the global board id as lo32 ^ hi32*C (fold_id).  hi32 is uniform over a
     // range of boards unless the range crosses a multiple of 2^32; the batch is cut there (at most
@@ -1021,6 +1040,20 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
 #undef QTTT_DISPATCH
 #undef QTTT_LAUNCH
     return launch_status();
+}
+
+int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+              uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+              uint8_t *terminated, int64_t n, void *stream) {
+    return launch_step(state, const_cast<uint8_t *>(actions), bits, seed, step_idx, board_offset, flags,
+                       reward, terminated, n, stream, false);
+}
+
+int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                     uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
+                     int64_t n, void *stream) {
+    return launch_step(state, actions_out, nullptr, seed, step_idx, board_offset, flags, reward,
+                       terminated, n, stream, true);
 }
 
 int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,

@@ -94,6 +94,22 @@ class VecEnv:
         self.step_idx += 1
         return self._reward, self._terminated
 
+    def step_random(self, actions_out=None):
+        """One step under the synthetic uniform-legal policy, policy and step fused in one kernel
+        (== sample_actions() followed by step_raw()).  Returns (reward, terminated); the actions
+        played are written to `actions_out` (u8[N,2]) if given."""
+        n = self.num_envs
+        if actions_out is not None and (actions_out.dtype != torch.uint8 or not actions_out.is_contiguous()
+                                        or actions_out.numel() != 2 * n or actions_out.device != self.state.device):
+            raise ValueError("actions_out must be a contiguous uint8 device tensor of shape (N, 2)")
+        with torch.cuda.device(self.device):
+            rc = self._lib.qttt_step_random(self.state.data_ptr(), self.seed, self.step_idx, self.board_offset,
+                                            self._flags(), _ptr(actions_out), self._reward.data_ptr(),
+                                            self._terminated.data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_step_random")
+        self.step_idx += 1
+        return self._reward, self._terminated
+
     def step_many(self, actions, bits=None, reward=None, terminated=None, fused=False):
         """T consecutive steps from pre-recorded device tensors actions u8[T,N,2] (bits u8[T,N]),
         enqueued from C with no per-step host work.  With `reward`/`terminated` of shape [T,N]

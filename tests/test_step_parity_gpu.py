@@ -337,3 +337,28 @@ def test_fused_step_many_equals_step_by_step(n, with_bits):
     r_last, t_last = env2.step_many(actions, bits, fused=True)          # last step's outputs only
     assert torch.equal(r_last.view(torch.int32), r_ref[-1].view(torch.int32)) and torch.equal(t_last, t_ref[-1])
     assert torch.equal(env2.state, rec.state)
+
+
+@pytest.mark.parametrize("n", [1001, 65536])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_step_random_equals_policy_then_step(n, auto_reset):
+    """qttt_step_random (policy + step in one kernel) == qttt_sample_actions + qttt_step, and both
+    == the oracle."""
+    from qtttgym_amd import VecEnv
+    seed, off = 41, 3 * n
+    a_env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    b_env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    played = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(13):
+        acts = a_env.sample_actions()
+        r1, t1 = a_env.step_raw(acts)
+        r1, t1 = r1.clone(), t1.clone()
+        r2, t2 = b_env.step_random(played if t % 2 == 0 else None)
+        if t % 2 == 0:
+            assert torch.equal(played, acts), t
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(t1, t2), t
+        assert torch.equal(a_env.state, b_env.state), t
+        a_or = ob.sample_actions(seed, t, off, auto_reset)
+        ob.step(a_or, None, seed, t, off, auto_reset)
+    assert_same_as_oracle(b_env, ob)
