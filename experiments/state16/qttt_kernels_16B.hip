@@ -1,0 +1,1267 @@
+// qttt_kernels.hip — gfx950 (MI355X / CDNA4) kernels + the C ABI of include/qttt.h.
+//
+// Mapping: ONE LANE PER BOARD (64 boards per wavefront, BPL consecutive boards per lane),
+// everything in VGPRs, structure-of-arrays state so that every load/store of a wave is one
+// contiguous 16-byte-per-lane segment.  No MFMA; LDS holds one 512-byte lookup table.
+// DESIGN.md §2 explains why the wave-per-board mapping was rejected after measurement and why
+// the kernel is written for minimum VALU *instruction count* (measured issue cost ~4 cycles per
+// wave-instruction for this instruction mix, tools/valu_rates.cpp).
+//
+// Formulation — deliberately NOT the reference's algorithm:
+//   * the un-collapsed moves of a board form a forest on the 9 squares (a move that closes a
+//     cycle collapses its whole component at once, board.py:42-56).  The forest is kept ROOTED:
+//     nibble sq[v] of a non-classical square v is the round of the move joining v to its parent
+//     (0xF = root / isolated).  For a classical square, sq[v] is the round that landed there
+//     (= Board.board[v]).
+//   * QEvalClassic.eval (qeval.py:5-51: leaf-peel + forced walk round the cycle) is equivalent
+//     to: re-root the tree at the square t the closing move lands on (bit picks lo/hi), then
+//     every other square of the component receives its parent edge.  So a collapse is one path
+//     reversal + `classical |= component`; no per-edge work.
+//   * Board.qstructs (board.py:6) is cached as 4 slots x 9-bit square masks, in the reference's
+//     list order, so "same component?" is two shifts and an AND.
+//
+// Packed state, 16 B/board, planes A[s] u64 | B[s] u64 (s = n rounded up to 64):
+//   A : bits [0,54)  move queue of 6-bit move codes, newest move in bits 0..5: the move of round
+//                    t sits in field n-1-t (code = idx | (lo^hi)<<2, so code & 0x3C is the xor of
+//                    the two squares times 4; idx tells the <= 4 pairs with that xor apart)
+//       bits [54,62) comps bits 28..35 | 62 zero | 63 done (terminated after the last step)
+//   B : bits [0,36)  sq nibbles, stored COMPLEMENTED (nibble ^ 0xF, so 0 = root / isolated)
+//       bits [36,64) comps bits 0..27   (comps = 4 x 9-bit masks, slot k at bit 9k, list order)
+//   Not stored, derived each step from the nibbles: n = number of moves played = number of
+//   non-zero nibbles (a classical square holds its round, a non-root tree node its parent edge),
+//   and the classical mask = non-zero nibble AND in no component.
+//   The all-zero state is the empty board, so reset is a memset.
+//   The autofill of board.py:22-25 is IMPLICIT: a board with exactly 8 classical squares stands
+//   for the reference state in which the 9th square holds round 8 and moves ends with (idx,idx,8)
+//   (the autofill round is always 8); the cold kernels materialise it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "qttt.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#ifndef QTTT_BLOCK
+#define QTTT_BLOCK 512
+#endif
+#define QTTT_DEFAULT_BPL 2
+#ifndef QTTT_TPL
+#define QTTT_TPL 1      // tiles of QTTT_BLOCK lane-groups per workgroup (each lane: TPL x BPL boards)
+#endif
+
+namespace {
+
+constexpr u32 SLOT_LSB = 0x08040201u;      // bit 0 of each 9-bit comps slot
+
+// A1 / B1 = high words of planes A / B
+constexpr u32 A1_Q_MASK = 0x003FFFFFu;     // queue bits 32..53
+constexpr u32 A1_C8_SHIFT = 22;            // comps bits 28..35
+constexpr u32 A1_DONE = 0x80000000u;
+constexpr u32 B1_CLO_SHIFT = 4;            // comps bits 0..27 above the 9th nibble
+constexpr u32 STATE_BYTES = 16;
+
+struct Planes {
+    u64 *A;
+    u64 *B;
+};
+
+// plane stride: n rounded up to 64 boards, so every plane starts 512-byte aligned
+__host__ __device__ inline int64_t plane_stride(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
+__host__ __device__ inline Planes planes(void *state, int64_t n) {
+    Planes p;
+    const int64_t s = plane_stride(n);
+    p.A = reinterpret_cast<u64 *>(state);
+    p.B = p.A + s;
+    return p;
+}
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+// same-size raw integer type for a Vec, so cache-policy builtins (which want scalars / ext vectors)
+// can be applied to it
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+template <int BYTES> struct RawOf;
+template <> struct RawOf<1> { typedef uint8_t type; };
+template <> struct RawOf<2> { typedef uint16_t type; };
+template <> struct RawOf<4> { typedef u32 type; };
+template <> struct RawOf<8> { typedef u32x2 type; };
+template <> struct RawOf<16> { typedef u32x4 type; };
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+template <> struct RawOf<32> { typedef u32x8 type; };
+
+// Every access of the step kernel is streaming within a launch (each byte is touched once) and L2
+// contents do not survive to the next launch, so all of them carry the non-temporal hint
+// (measured: 8.68 -> 7.96 us per 1 M-board launch)
+template <typename V>
+__device__ __forceinline__ V load_stream(const V *p) {
+#ifndef QTTT_NO_NT
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+    V v;
+    __builtin_memcpy(&v, &r, sizeof(V));
+    return v;
+#else
+    return *p;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ void store_stream(V *p, const V &v) {
+#ifndef QTTT_NO_NT
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+#else
+    *p = v;
+#endif
+}
+
+#ifdef QTTT_DEBUG_STAMPS
+__device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench stamps)
+#endif
+
+// ------------------------------------------------------------------ 3-in-a-row lookup table
+// line_lut[m] = 0x7F iff the 9-bit square mask m contains one of the 8 lines of board.py:85-110.
+__host__ __device__ constexpr bool mask_has_line(u32 m) {
+    return (m & 0x007u) == 0x007u || (m & 0x038u) == 0x038u || (m & 0x1C0u) == 0x1C0u ||
+           (m & 0x049u) == 0x049u || (m & 0x092u) == 0x092u || (m & 0x124u) == 0x124u ||
+           (m & 0x054u) == 0x054u || (m & 0x111u) == 0x111u;
+}
+
+struct LineLut {
+    uint8_t b[512];
+    constexpr LineLut() : b() {
+        for (u32 m = 0; m < 512; ++m) b[m] = mask_has_line(m) ? 0x7F : 0;   // 0x7F << 23 = 1.0f
+    }
+};
+__constant__ LineLut g_line_lut = LineLut();
+
+// ------------------------------------------------------------------ 6-bit move codes
+// A move is an unordered pair lo < hi of squares (autofill moves are never stored, they are
+// implicit).  code = idx | (lo^hi) << 2: the xor of the two squares (1..15) in the high four bits,
+// so that the re-rooting walk gets "(lo^hi)*4" as `code & 0x3C` with no table; idx (0..3) numbers
+// the pairs with that xor by ascending lo (xor 1..7: four pairs each, xor 8..15: one each = 36).
+struct MoveCode {
+    uint8_t enc[256];   // [lo | hi<<4] -> code   (lo < hi <= 8; 0 elsewhere)
+    uint8_t dec[64];    // code -> lo | hi<<4     (0xFF for the unused codes)
+    constexpr MoveCode() : enc(), dec() {
+        for (int c = 0; c < 64; ++c) dec[c] = 0xFF;
+        for (int x = 1; x < 16; ++x) {
+            int idx = 0;
+            for (int lo = 0; lo < 9; ++lo) {
+                const int hi = lo ^ x;
+                if (hi <= lo || hi > 8) continue;
+                const int code = idx | (x << 2);
+                enc[lo | (hi << 4)] = (uint8_t)code;
+                dec[code] = (uint8_t)(lo | (hi << 4));
+                ++idx;
+            }
+        }
+    }
+};
+__constant__ MoveCode g_move_code = MoveCode();
+
+// LDS table of the step kernels: [0,512) line_lut, [512,768) MoveCode::enc
+constexpr u32 STEP_LUT_BYTES = 768;
+constexpr u32 STEP_LUT_ENC = 512;
+__device__ inline void fill_step_lut(uint8_t *lut) {
+    for (u32 w = threadIdx.x; w < STEP_LUT_BYTES / 4; w += QTTT_BLOCK)
+        reinterpret_cast<u32 *>(lut)[w] = w < 128u ? reinterpret_cast<const u32 *>(g_line_lut.b)[w]
+                                                   : reinterpret_cast<const u32 *>(g_move_code.enc)[w - 128u];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ counter hash (the build's
+// synthetic-input spec)
+__host__ __device__ inline u32 lowbias32(u32 x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline u64 launch_key(u64 seed, u32 step_idx) {
+    return splitmix64(seed ^ ((u64)step_idx * 0xD1B54A32D192ED03ull));
+}
+__host__ __device__ inline u32 fold_id(u64 board_id) {
+    u32 f = (u32)board_id;
+    u32 h = (u32)(board_id >> 32);
+    if (h) f ^= h * 0x9E3779B9u;           // never taken below 2^32 boards: no multiply on the hot path
+    return f;
+}
+// top bit of lowbias32(x): the final xor-shift cannot change bit 31, so it is skipped
+__device__ inline u32 collapse_bit_of(u32 x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    return x >> 31;
+}
+
+// ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
+// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4;
+// nth_bit[m][r]: index of the r-th set bit of the 9-bit mask m.  The k-th legal action of a board
+// with empty-square mask m is (nth_bit[m][i], nth_bit[m][j]).
+struct PolicyLut {
+    uint8_t rank_pair[10 * 36];
+    uint8_t nth_bit[512 * 9];
+    uint8_t pad[4];
+    constexpr PolicyLut() : rank_pair(), nth_bit(), pad() {
+        for (int e = 0; e < 10; ++e) {
+            int k = 0;
+            for (int i = 0; i < e; ++i)
+                for (int j = i + 1; j < e; ++j) rank_pair[e * 36 + k++] = (uint8_t)(i | (j << 4));
+            for (; k < 36; ++k) rank_pair[e * 36 + k] = 0;
+        }
+        for (int m = 0; m < 512; ++m) {
+            int r = 0;
+            for (int v = 0; v < 9; ++v)
+                if (m >> v & 1) nth_bit[m * 9 + r++] = (uint8_t)v;
+            for (; r < 9; ++r) nth_bit[m * 9 + r] = 0;
+        }
+    }
+};
+__constant__ PolicyLut g_policy_lut = PolicyLut();
+constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 512 * 9 + 4) / 4;
+
+__device__ inline void fill_policy_lut(uint8_t *dst) {
+    const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
+    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += QTTT_BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
+}
+
+// the policy's action for a board whose empty-square mask is `empty`, from hash word h2: lo | hi<<8
+__device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32 h2) {
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 k = __umulhi(h2, (e * (e - 1u)) >> 1);
+    const u32 ij = plut[e * 36u + k];
+    const uint8_t *nth = plut + 360u + empty * 9u;
+    return (u32)nth[ij & 0xFu] | ((u32)nth[ij >> 4] << 8);
+}
+
+// classical squares of a packed board: non-zero nibble and in no component (see the layout notes)
+__device__ __forceinline__ u32 classical_mask(u32 A1, u32 B0, u32 B1) {
+    u32 t = B0 | (B0 >> 1);
+    t |= t >> 2;
+    t &= 0x11111111u;
+    const u32 nz = __builtin_amdgcn_udot8(t, 0x00008421u, 0u, false) |
+                   (__builtin_amdgcn_udot8(t, 0x84210000u, 0u, false) << 4) |
+                   ((((B1 & 0xFu) + 0xFu) >> 4) << 8);
+    const u32 c8 = (A1 >> A1_C8_SHIFT) & 0xFFu;
+    const u32 clo = (B1 >> B1_CLO_SHIFT) | (c8 << 28);
+    const u32 in_comp = (clo | (clo >> 9) | (clo >> 18) | ((clo >> 27) | (c8 >> 4 << 5))) & 0x1FFu;
+    return nz & ~in_comp;
+}
+
+// ====================================================================== the hot path
+// One Env.step (env.py:34-53) on the board held in (A0,A1,B0,B1).  `lut` is the LDS table of
+// fill_step_lut.  Returns 0x7F iff a completed line exists afterwards (else 0); A1's done bit is
+// updated.
+template <bool AUTO_RESET>
+__device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32 act, u32 bit,
+                                         const uint8_t *lut) {
+    if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
+        const u32 keep = ~(u32)((int)A1 >> 31);         // 0 iff done
+        A0 &= keep;
+        A1 &= keep;
+        B0 &= keep;
+        B1 &= keep;
+    }
+    // ---- fields that are derived, not stored ----
+    // nz: squares whose nibble is non-zero (classical, or a tree node with a parent edge)
+    u32 t = B0 | (B0 >> 1);
+    t |= t >> 2;
+    t &= 0x11111111u;
+    const u32 nz = __builtin_amdgcn_udot8(t, 0x00008421u, 0u, false) |
+                   (__builtin_amdgcn_udot8(t, 0x84210000u, 0u, false) << 4) |
+                   ((((B1 & 0xFu) + 0xFu) >> 4) << 8);
+    const u32 c8 = (A1 >> A1_C8_SHIFT) & 0xFFu;
+    u32 clo = (B1 >> B1_CLO_SHIFT) | (c8 << 28);        // comps bits 0..31
+    u32 chi = c8 >> 4;                                  // comps bits 32..35
+    const u32 in_comp = (clo | (clo >> 9) | (clo >> 18) | ((clo >> 27) | (chi << 5))) & 0x1FFu;
+    u32 cl = nz & ~in_comp;                             // classical squares
+    const u32 a = act & 0xFFu, b = act >> 8;            // action[0], action[1] (env.py:37-38)
+    const u32 lo = min(a, b), hi = max(a, b);           // board.py:16-18
+    const u32 pm = (1u << (lo & 31u)) | (1u << (hi & 31u));
+    // board.py:10-15 (+ IndexError for >8, swallowed at env.py:41): reject before mutating
+    if (hi < 9u && lo != hi && (pm & cl) == 0u) {
+        const u32 n = (u32)__builtin_popcount(nz);       // moves played so far
+        u64 comps = (u64)clo | ((u64)chi << 32);
+        const u32 mlo = (u32)(comps >> lo) & SLOT_LSB;   // slot holding lo (board.py:28-33)
+        const u32 mhi = (u32)(comps >> hi) & SLOT_LSB;   // slot holding hi (board.py:35-40)
+        const bool has_lo = mlo != 0u, has_hi = mhi != 0u;
+        const bool cyc = (mlo & mhi) != 0u;              // board.py:42: same component -> cycle
+        // x: the square that becomes the child end of the new edge; on a cycle it is the square
+        // the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi), which becomes the root
+        const u32 x4 = ((cyc && bit == 0u) ? lo : hi) * 4u;
+        u64 B = (u64)B0 | ((u64)B1 << 32);               // sq nibbles (complemented) = bits 0..35
+        u64 Q = (u64)A0 | ((u64)(A1 & A1_Q_MASK) << 32); // move queue
+        {   // re-root x's tree at x: reverse the parent edges along the path x -> old root.
+            // The queue field of round e is n-1-e = ec + n - 16 for the stored ec = e^15, and
+            // (code & 0x3C) of that field is (lo^hi)*4: the other end of edge e is one xor away.
+            const u32 base6 = 6u * n - 96u;
+            // x itself receives this move as its parent edge (complemented round n), every later
+            // node on the path receives the edge its child used to have
+            u32 v4 = x4, prev = 0xFu ^ n;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const u32 ec = (u32)(B >> v4) & 0xFu;
+                B ^= (u64)(ec ^ prev) << v4;             // sq[v] = prev
+                if (ec == 0u) break;                     // v was the root
+                v4 ^= (u32)(Q >> (ec * 6u + base6)) & 0x3Cu;
+                prev = ec;
+            }
+        }
+        B0 = (u32)B;
+        B1 = (u32)(B >> 32);
+        // board.py:19: append to the queue
+        Q = (Q << 6) | (u64)lut[STEP_LUT_ENC + (lo | (hi << 4))];
+        // ---- board.py:42-69 on the cached qstructs, all three cases in one straight line ----
+        const u32 shi = (u32)__builtin_ctz(mhi | 0x80000000u);          // 31 when hi is in no slot
+        const u32 c1 = has_hi ? (u32)(comps >> shi) & 0x1FFu : 0u;      // component of hi
+        const bool uni = has_lo && has_hi && !cyc;                      // board.py:58-61
+        // first empty slot (slots are compact): 9 * number of non-empty slots among 0..2
+        const u32 nzs = (((clo & 0x03FDFEFFu) + 0x03FDFEFFu) | clo) & 0x04020100u;
+        const u32 s_new = (u32)__builtin_popcount(nzs) * 9u;
+        const u32 slo = (u32)__builtin_ctz(mlo | 0x80000000u);
+        const u32 sT = has_lo ? slo : (has_hi ? shi : s_new);           // board.py:62-69
+        comps |= (u64)(pm | (uni ? c1 : 0u)) << sT;
+        // pop hi's slot on a cycle (board.py:56) or a union (board.py:61)
+        const u32 low = ((cyc || uni) ? mhi : 0u) - 1u;                 // all ones = keep everything
+        const u32 lowh = (u32)((int)low >> 31);
+        const u64 sh9 = comps >> 9;
+        clo = ((u32)comps & low) | ((u32)sh9 & ~low);
+        chi = ((u32)(comps >> 32) & lowh) | ((u32)(sh9 >> 32) & ~lowh);
+        // board.py:44-56 + qeval.py:5-51: on a cycle every square of the component goes classical
+        // and already holds its parent edge's round; x holds the closing move's round
+        cl |= cyc ? c1 : 0u;
+        // repack
+        B1 = (B1 & 0xFu) | (clo << B1_CLO_SHIFT);
+        A0 = (u32)Q;
+        A1 = ((u32)(Q >> 32) & A1_Q_MASK) | ((((clo >> 28) | (chi << 4)) & 0xFFu) << A1_C8_SHIFT);
+    }
+    // board.py:71-115 reduced to "does any line exist" (all that env.py:49,51 need): parity of the
+    // round on each classical square -> X / O masks -> table lookup.  Nibbles are complemented, so
+    // a set low bit means an EVEN round (X).  Eight classical squares = the autofill of
+    // board.py:22-25 is due: the ninth square counts as X (round 8) and the game is over.
+    const u32 par = B0 & 0x11111111u;
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((B1 & 1u) << 8);
+    const u32 pc = (u32)__builtin_popcount(cl);
+    const u32 fill = pc == 8u ? (cl ^ 0x1FFu) : 0u;
+    const u32 win = (u32)lut[(cl & even) | fill] | (u32)lut[cl & ~even];
+    // env.py:51: a line, or len(moves) > 8  <=>  at least 8 classical squares
+    A1 = (A1 & ~A1_DONE) | ((win != 0u || pc >= 8u) ? A1_DONE : 0u);
+    return win;
+}
+
+// BPL boards per lane: lane j owns boards [j*BPL, (j+1)*BPL), so every plane is read and written
+// with 16-byte vector accesses that are contiguous across the wave.  Addresses are a block-uniform
+// 64-bit base (scalar unit) plus a 32-bit lane offset.
+// SAMPLE: the action is not read but drawn in the kernel from the uniform-legal policy (and written to
+// `actions` when that is not null) — qttt_sample_actions + qttt_step in one launch.
+template <int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false>
+__global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
+    u64 *__restrict__ pA, u64 *__restrict__ pB,
+    uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi,
+    u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    int64_t i_begin, int64_t n_groups) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[STEP_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
+#ifdef QTTT_DEBUG_STAMPS
+    const u64 st0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    typedef Vec<u64, BPL> V64;
+    typedef Vec<u32, BPL> V32;
+    typedef Vec<uint16_t, BPL> V16;
+    typedef Vec<uint8_t, BPL> V8;
+    // a block owns QTTT_TPL consecutive tiles of QTTT_BLOCK lane-groups; lane t owns group t of each
+    const int64_t jb = (int64_t)blockIdx.x * (QTTT_BLOCK * QTTT_TPL);   // first lane-group of the block
+    const int64_t ib = i_begin + jb * BPL;                              // first board of the block
+    const int64_t left = n_groups - jb;                                 // lane-groups left from here on
+    // issue all streaming loads first, fill the lookup table while they are in flight
+    V64 a[QTTT_TPL], b[QTTT_TPL];
+    V16 act[QTTT_TPL];
+    V8 bt[QTTT_TPL];
+    u32 g[QTTT_TPL];
+    bool active[QTTT_TPL];
+#pragma unroll
+    for (int q = 0; q < QTTT_TPL; ++q) {
+        const u32 gq = (u32)q * QTTT_BLOCK + threadIdx.x;
+        active[q] = (int64_t)gq < left;
+        g[q] = active[q] ? gq : 0u;                                     // idle lanes re-read group 0
+#ifndef QTTT_PLAIN_STATE_LD
+        a[q] = load_stream(&reinterpret_cast<const V64 *>(pA + ib)[g[q]]);
+        b[q] = load_stream(&reinterpret_cast<const V64 *>(pB + ib)[g[q]]);
+#else
+        a[q] = reinterpret_cast<const V64 *>(pA + ib)[g[q]];
+        b[q] = reinterpret_cast<const V64 *>(pB + ib)[g[q]];
+#endif
+        if (!SAMPLE) act[q] = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g[q]]);
+        if (HAS_BITS) bt[q] = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g[q]]);
+    }
+    if (SAMPLE) fill_policy_lut(plut);
+    fill_step_lut(lut);                                                 // ends with the workgroup barrier
+#ifdef QTTT_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+    for (int q = 0; q < QTTT_TPL; ++q) {
+        if (!active[q]) continue;
+        V32 rw;
+        V8 tm;
+        const u32 id0 = id_base + ((u32)jb + g[q]) * BPL;               // low 32 bits of the global board id
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            u32 A0 = (u32)a[q].v[k], A1 = (u32)(a[q].v[k] >> 32);
+            u32 B0 = (u32)b[q].v[k], B1 = (u32)(b[q].v[k] >> 32);
+            u32 bit, av;
+            if (SAMPLE) {
+                // the policy sees the board the step will act on: a finished board counts as empty
+                const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
+                const u32 h2 = lowbias32(h1 ^ key_hi);
+                const u32 empty = (AUTO_RESET && (A1 >> 31)) ? 0x1FFu : ~classical_mask(A1, B0, B1) & 0x1FFu;
+                av = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
+                act[q].v[k] = (uint16_t)av;
+                bit = h1 >> 31;
+            } else {
+                av = act[q].v[k];
+                if (HAS_BITS) bit = bt[q].v[k] & 1u;
+                else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+            }
+            const u32 win = step_core<AUTO_RESET>(A0, A1, B0, B1, av, bit, lut);
+            a[q].v[k] = (u64)A0 | ((u64)A1 << 32);
+            b[q].v[k] = (u64)B0 | ((u64)B1 << 32);
+            rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f
+            tm.v[k] = (uint8_t)(A1 >> 31);
+        }
+#ifndef QTTT_PLAIN_STATE_ST
+        store_stream(&reinterpret_cast<V64 *>(pA + ib)[g[q]], a[q]);
+        store_stream(&reinterpret_cast<V64 *>(pB + ib)[g[q]], b[q]);
+#else
+        reinterpret_cast<V64 *>(pA + ib)[g[q]] = a[q];
+        reinterpret_cast<V64 *>(pB + ib)[g[q]] = b[q];
+#endif
+        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g[q]], act[q]);
+        store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g[q]], rw);
+        store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g[q]], tm);
+    }
+#ifdef QTTT_DEBUG_STAMPS
+    const u64 st2 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st3 = __builtin_amdgcn_s_memrealtime();
+    if (g_debug_stamps && (threadIdx.x & 63) == 0) {
+        u64 *o = g_debug_stamps + ((int64_t)blockIdx.x * (QTTT_BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+#endif
+}
+
+// T consecutive steps in ONE launch (qttt_step_many with QTTT_FLAG_FUSED): the boards stay in
+// registers, only the per-step streams move (2 B action in, 5 B reward/terminated out per step), so
+// the loop is VALU-bound and pays one launch instead of T.  Same results as T launches of
+// step_kernel; meant for replay / evaluation where the actions are known up front (a policy that
+// looks at the state between steps needs the one-launch-per-step form).
+template <bool HAS_BITS, bool AUTO_RESET>
+__global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
+    u64 *__restrict__ pA, u64 *__restrict__ pB,
+    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u64 seed, u32 step_idx0,
+    u32 id_hi_fold, u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    int64_t out_stride, int64_t n, int32_t n_steps) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[STEP_LUT_BYTES];
+    fill_step_lut(lut);
+    const int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 A = pA[i], B = pB[i];
+    u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32);
+    const u32 id = id_base + (u32)i;
+    u32 win = 0;
+    for (int32_t t = 0; t < n_steps; ++t) {
+        const u32 act = load_stream(&actions[(int64_t)t * n + i]);
+        u32 bit;
+        if (HAS_BITS) bit = load_stream(&bits[(int64_t)t * n + i]) & 1u;
+        else bit = collapse_bit_of(id ^ ((u32)launch_key(seed, step_idx0 + (u32)t) ^ id_hi_fold));
+        win = step_core<AUTO_RESET>(A0, A1, B0, B1, act, bit, lut);
+        if (out_stride != 0 || t == n_steps - 1) {
+            const u32 rwv = 0x80000000u | (win << 23);
+            const uint8_t tmv = (uint8_t)(A1 >> 31);
+            store_stream(&reward_bits[(int64_t)t * out_stride + i], rwv);
+            store_stream(&terminated[(int64_t)t * out_stride + i], tmv);
+        }
+    }
+    pA[i] = (u64)A0 | ((u64)A1 << 32);
+    pB[i] = (u64)B0 | ((u64)B1 << 32);
+}
+
+// ====================================================================== cold paths
+// Friendly unpacked form for the kernels that are not on the hot path.  Everything is kept in
+// packed words with shift accessors — no per-thread arrays: runtime-indexed arrays would live in
+// scratch memory, and the scratch-backed version of these kernels returned an occasional wrong
+// element under 512-thread workgroups on this part (tools/flake_probe.py).
+// tests/test_abi_and_host.py asserts that no kernel of this file uses scratch.
+struct Cold {
+    u32 n;          // n_moves, autofill move included (derived on unpack)
+    u32 cl;         // classical mask, autofilled square included (derived on unpack)
+    u32 done;
+    u64 mvq;        // moves of rounds 0..7: byte t = lo | hi<<4
+    u32 mv8;        // move of round 8
+    u64 sq;         // 9 nibbles, true values (0xF = root / isolated / empty)
+    u64 comps;      // 4 x 9-bit masks, list order
+    __device__ u32 mv(u32 t) const { return t >= 8u ? mv8 : (u32)(mvq >> (t * 8u)) & 0xFFu; }
+    __device__ void set_mv(u32 t, u32 m) {
+        if (t >= 8u) mv8 = m & 0xFFu;
+        else mvq = (mvq & ~(0xFFull << (t * 8u))) | ((u64)(m & 0xFFu) << (t * 8u));
+    }
+    __device__ u32 sqv(u32 v) const { return (u32)(sq >> (v * 4u)) & 0xFu; }
+    __device__ void set_sq(u32 v, u32 x) { sq = (sq & ~(0xFull << (v * 4u))) | ((u64)(x & 0xFu) << (v * 4u)); }
+    __device__ u32 comp(u32 k) const { return (u32)(comps >> (9u * k)) & 0x1FFu; }
+};
+
+__device__ __forceinline__ void cold_unpack(u64 A, u64 B, Cold &s) {
+    const u32 A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32);
+    s.done = A1 >> 31;
+    s.sq = (B & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;                // stored complemented
+    s.comps = (B >> 36) | ((u64)((A1 >> A1_C8_SHIFT) & 0xFFu) << 28);
+    s.cl = classical_mask(A1, B0, B1);
+    // moves played = non-zero nibbles (classical squares + tree nodes with a parent edge)
+    s.n = 0;
+    for (u32 v = 0; v < 9; ++v) s.n += s.sqv(v) != 0xFu;
+    s.mvq = 0;
+    s.mv8 = 0;
+    for (u32 t = 0; t < s.n; ++t) {
+        const u32 q = s.n - 1u - t;                              // queue field of round t
+        s.set_mv(t, g_move_code.dec[(u32)(A >> (q * 6u)) & 0x3Fu]);
+    }
+    // materialise the implicit autofill (board.py:22-25): exactly 8 classical squares
+    if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {
+        const u32 idx = (u32)__builtin_ctz(~s.cl);
+        s.set_sq(idx, s.n);                                      // board[idx] = len(self.moves)
+        s.cl |= 1u << idx;
+        s.set_mv(s.n, idx | (idx << 4));                         // moves.append((idx, idx, len))
+        s.n += 1u;
+    }
+}
+
+__device__ __forceinline__ void cold_pack(const Cold &in, u64 &A, u64 &B) {
+    Cold s = in;
+    // strip an explicit autofill move (lo == hi, always the last one) back to the implicit form
+    if (s.n >= 1u && s.n <= 9u) {
+        const u32 last = s.mv(s.n - 1u);
+        if ((last & 0xFu) == (last >> 4)) {
+            const u32 idx = last & 0xFu;
+            if (idx < 9u) {
+                s.cl &= ~(1u << idx);
+                s.set_sq(idx, 0xFu);
+            }
+            s.n -= 1u;
+        }
+    }
+    u64 Q = 0;
+    for (u32 t = 0; t < s.n && t < 9u; ++t) {
+        const u32 m = s.mv(t);
+        const u32 lo = min(m & 0xFu, m >> 4), hi = max(m & 0xFu, m >> 4);
+        const u32 code = (lo < hi && hi < 9u) ? (u32)g_move_code.enc[lo | (hi << 4)] : 0u;
+        Q |= (u64)code << ((s.n - 1u - t) * 6u);
+    }
+    const u64 sqc = (s.sq & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;
+    const u64 comps = s.comps & 0xFFFFFFFFFull;
+    B = sqc | ((comps & 0x0FFFFFFFull) << 36);
+    A = (Q & 0x3FFFFFFFFFFFFFull) | ((comps >> 28) << 54) | (s.done ? (1ull << 63) : 0ull);
+}
+
+// one line of board.py:85-110: p1/p2 = min over completed lines of the max round in the line
+__device__ __forceinline__ void cold_line(const Cold &s, u32 X, u32 O, u32 L, int &p1, int &p2) {
+    int mx = -1;
+    for (u32 v = 0; v < 9; ++v)
+        if (L >> v & 1u) mx = max(mx, (int)s.sqv(v));
+    const bool c1 = (X & L) == L, c2 = !c1 && (O & L) == L;     // selects, not a choice of address:
+    p1 = c1 ? min(p1, mx) : p1;                                  // keeps p1/p2 in registers
+    p2 = c2 ? min(p2, mx) : p2;
+}
+
+__device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) {
+    // board.py:71-115, lines in the reference's order (rows, cols, 2-4-6, 0-4-8)
+    u32 X = 0, O = 0;
+    for (u32 v = 0; v < 9; ++v)
+        if (s.cl >> v & 1u) { if (s.sqv(v) & 1u) O |= 1u << v; else X |= 1u << v; }
+    p1 = 10;
+    p2 = 10;
+    cold_line(s, X, O, 0x007u, p1, p2);
+    cold_line(s, X, O, 0x038u, p1, p2);
+    cold_line(s, X, O, 0x1C0u, p1, p2);
+    cold_line(s, X, O, 0x049u, p1, p2);
+    cold_line(s, X, O, 0x092u, p1, p2);
+    cold_line(s, X, O, 0x124u, p1, p2);
+    cold_line(s, X, O, 0x054u, p1, p2);
+    cold_line(s, X, O, 0x111u, p1, p2);
+    if (p1 >= 10) p1 = -1;
+    if (p2 >= 10) p2 = -1;
+}
+
+#define QTTT_COLD_BLOCK 256
+
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(
+    const u64 *pA, const u64 *pB, int8_t *classical, uint8_t *q_p1,
+    uint8_t *q_p1_len, uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_unpack(pA[i], pB[i], s);
+    for (u32 v = 0; v < 9; ++v)                                   // env.py:71,82
+        classical[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sqv(v) : (int8_t)-1;
+    u32 n1 = 0, n2 = 0;
+    for (u32 t = 0; t < s.n; ++t) {                               // env.py:72-77
+        const u32 m = s.mv(t);
+        const u32 lo = m & 0xFu, hi = m >> 4;
+        if (s.cl >> lo & 1u) continue;                            // round t is on the board
+        if (t & 1u) {
+            q_p2[i * 8 + n2 * 2] = (uint8_t)lo;
+            q_p2[i * 8 + n2 * 2 + 1] = (uint8_t)hi;
+            ++n2;
+        } else {
+            q_p1[i * 10 + n1 * 2] = (uint8_t)lo;
+            q_p1[i * 10 + n1 * 2 + 1] = (uint8_t)hi;
+            ++n1;
+        }
+    }
+    for (u32 k = n1; k < 5; ++k) q_p1[i * 10 + k * 2] = q_p1[i * 10 + k * 2 + 1] = 255;
+    for (u32 k = n2; k < 4; ++k) q_p2[i * 8 + k * 2] = q_p2[i * 8 + k * 2 + 1] = 255;
+    q_p1_len[i] = (uint8_t)n1;
+    q_p2_len[i] = (uint8_t)n2;
+    turn[i] = (uint8_t)(s.n & 1u);                                // env.py:83
+}
+
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
+    const u64 *pA, const u64 *pB, int8_t *p1_round, int8_t *p2_round, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_unpack(pA[i], pB[i], s);
+    int p1, p2;
+    cold_check_win(s, p1, p2);
+    p1_round[i] = (int8_t)p1;
+    p2_round[i] = (int8_t)p2;
+}
+
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
+    const u64 *pA, const u64 *pB, uint8_t *moves, uint8_t *n_moves,
+    int8_t *board, uint16_t *qmask, uint8_t *n_q, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_unpack(pA[i], pB[i], s);
+    for (u32 t = 0; t < 9; ++t) {
+        const bool used = t < s.n;
+        const u32 m = s.mv(t);
+        moves[i * 18 + t * 2] = used ? (uint8_t)(m & 0xFu) : (uint8_t)255;
+        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)(m >> 4) : (uint8_t)255;
+    }
+    n_moves[i] = (uint8_t)s.n;
+    for (u32 v = 0; v < 9; ++v)
+        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sqv(v) : (int8_t)-1;
+    u32 nq = 0;
+    for (u32 k = 0; k < 4; ++k) {
+        qmask[i * 4 + k] = (uint16_t)s.comp(k);
+        nq += s.comp(k) != 0u;
+    }
+    n_q[i] = (uint8_t)nq;
+}
+
+// Builds the packed state (incl. the rooted forest) from Board attributes assigned by a caller
+// (mcts.py:11-17,241 assign .board/.moves/.qstructs directly).  Not a hot path.
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
+    u64 *pA, u64 *pB, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
+    const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    s.n = min((u32)n_moves[i], 9u);
+    s.cl = 0;
+    s.mvq = 0;
+    s.mv8 = 0;
+    for (u32 t = 0; t < s.n; ++t)
+        s.set_mv(t, (u32)(moves[i * 18 + t * 2] & 0xFu) | ((u32)(moves[i * 18 + t * 2 + 1] & 0xFu) << 4));
+    s.sq = 0xFFFFFFFFFull;
+    for (u32 v = 0; v < 9; ++v) {
+        const int bv = board[i * 9 + v];
+        if (bv >= 0) {
+            s.cl |= 1u << v;
+            s.set_sq(v, (u32)bv & 0xFu);
+        }
+    }
+    // qstructs are a function of (moves, board) in every state the reference can reach: the list
+    // the reference would hold is rebuilt by replaying board.py:58-69 over the un-collapsed moves
+    // in round order (collapsed components never merged with surviving ones, and list.pop keeps the
+    // survivors' relative order).  The caller's qmask / n_q are therefore not needed; a caller
+    // that forgot to copy .qstructs (mcts.py:159-166 builds its root that way) gets the consistent
+    // state instead of an inconsistent one.  The packed form needs this consistency: its classical
+    // mask is derived as "non-zero nibble and in no component".
+    (void)qmask;
+    (void)n_q;
+    s.comps = 0;
+    for (u32 t = 0; t < s.n; ++t) {
+        const u32 m = s.mv(t);
+        const u32 lo = m & 0xFu, hi = m >> 4;
+        if (lo == hi || lo > 8u || hi > 8u || (s.cl >> lo & 1u) || (s.cl >> hi & 1u)) continue;
+        u32 k0 = 4, k1 = 4, used = 0;
+        for (u32 k = 0; k < 4; ++k) {
+            const u32 c = s.comp(k);
+            used += c != 0u;
+            if (k0 == 4u && (c >> lo & 1u)) k0 = k;
+            if (k1 == 4u && (c >> hi & 1u)) k1 = k;
+        }
+        if (k0 < 4u && k1 < 4u) {
+            if (k0 == k1) continue;                              // cannot happen among live moves
+            s.comps |= (u64)s.comp(k1) << (9u * k0);             // board.py:60
+            const u64 low = (1ull << (9u * k1)) - 1ull;          // board.py:61 pop(m1)
+            s.comps = (s.comps & low) | ((s.comps >> 9) & ~low);
+        } else {
+            const u32 k = k0 < 4u ? k0 : (k1 < 4u ? k1 : used);  // board.py:62-69
+            if (k < 4u) s.comps |= (u64)((1u << lo) | (1u << hi)) << (9u * k);
+        }
+    }
+    // root every tree of live edges: grow from the lowest square of each tree
+    u32 rooted = 0;
+    for (int pass = 0; pass < 9; ++pass) {
+        bool grew = false;
+        u32 cand = 0;
+        for (u32 t = 0; t < s.n; ++t) {
+            const u32 m = s.mv(t);
+            const u32 lo = m & 0xFu, hi = m >> 4;
+            if (lo == hi || lo > 8u || hi > 8u || (s.cl >> lo & 1u) || (s.cl >> hi & 1u)) continue;
+            const bool rl = rooted >> lo & 1u, rh = rooted >> hi & 1u;
+            if (rl && !rh) { s.set_sq(hi, t); rooted |= 1u << hi; grew = true; }
+            else if (rh && !rl) { s.set_sq(lo, t); rooted |= 1u << lo; grew = true; }
+            cand |= (1u << lo) | (1u << hi);
+        }
+        if (!grew) {
+            cand &= ~rooted;                 // start a new tree at the lowest un-rooted square
+            if (cand == 0u) break;
+            rooted |= cand & (0u - cand);
+        }
+    }
+    int p1, p2;
+    cold_check_win(s, p1, p2);
+    s.done = (p1 > 0 || p2 > 0 || s.n > 8u) ? 1u : 0u;
+    u64 A, B;
+    cold_pack(s, A, B);
+    pA[i] = A;
+    pB[i] = B;
+}
+
+// legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
+__global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
+    const u64 *pA, const u64 *pB, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset,
+    uint16_t *actions, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    fill_policy_lut(plut);
+    __syncthreads();
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u32 A1 = (u32)(pA[i] >> 32);
+    const u64 B = pB[i];
+    const u32 cl = (auto_reset && (A1 >> 31)) ? 0u : classical_mask(A1, (u32)B, (u32)(B >> 32));
+    const u32 empty = ~cl & 0x1FFu;
+    const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
+    const u32 h2 = lowbias32(h1 ^ key_hi);
+    // fewer than two empty squares: rank_pair gives (0,0) and nth_bit[..][0] twice -> a == b, a noop;
+    // the spec says (0,0)
+    const u32 act = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
+    actions[i] = (uint16_t)act;
+}
+
+// ====================================================================== §8(f) rows
+// ind2move (mcts.py:339-343): lexicographic pairs (0,1),(0,2)..(7,8) as lo | hi<<4
+struct PairLut {
+    uint8_t b[36];
+    constexpr PairLut() : b() {
+        int a = 0;
+        for (int i = 0; i < 9; ++i)
+            for (int j = i + 1; j < 9; ++j) b[a++] = (uint8_t)(i | (j << 4));
+    }
+};
+__constant__ PairLut g_pair_lut = PairLut();
+
+// GameState.actions (mcts.py:20-27): action a is listed iff both its squares are classical-empty
+__device__ __forceinline__ u64 cold_legal_mask(const Cold &s) {
+    u64 m = 0;
+    for (int a = 0; a < 36; ++a) {
+        const u32 pr = g_pair_lut.b[a];
+        if (!((s.cl >> (pr & 0xFu)) & 1u) && !((s.cl >> (pr >> 4)) & 1u)) m |= 1ull << a;
+    }
+    return m;
+}
+
+// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal
+__device__ __forceinline__ void cold_update_winner(const Cold &s, int &winner, int &terminal) {
+    int p1, p2;
+    cold_check_win(s, p1, p2);
+    winner = -1;
+    terminal = 0;
+    if (p1 > 0 && p2 > 0) { winner = p1 < p2; terminal = 1; }
+    else if (p2 < 0 && p1 > 0) { winner = 1; terminal = 1; }
+    else if (p1 < 0 && p2 > 0) { winner = 0; terminal = 1; }
+    terminal = (s.n == 9u) || terminal;
+}
+
+// GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
+// (Objects/tupleobject.c tuplehash, xxHash-style; hash(int) = the int, hash(-1) = -2).
+__device__ inline u64 py_tuple_acc(u64 acc, u64 lane) {
+    acc += lane * 14029467366897019727ull;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * 11400714785074694791ull;
+}
+__device__ inline u64 py_tuple_fin(u64 acc, u64 len) {
+    acc += len ^ (2870177450012600261ull ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+__device__ __forceinline__ int64_t cold_py_hash(const Cold &s) {
+    u64 acc = 2870177450012600261ull;
+    for (u32 v = 0; v < 9; ++v)
+        acc = py_tuple_acc(acc, (s.cl >> v & 1u) ? (u64)s.sqv(v) : (u64)(int64_t)-2);
+    for (u32 t = 0; t < s.n; ++t) {
+        u64 in = 2870177450012600261ull;
+        in = py_tuple_acc(in, (u64)(s.mv(t) & 0xFu));
+        in = py_tuple_acc(in, (u64)(s.mv(t) >> 4));
+        in = py_tuple_acc(in, (u64)t);
+        acc = py_tuple_acc(acc, py_tuple_fin(in, 3));
+    }
+    return (int64_t)py_tuple_fin(acc, 9u + s.n);
+}
+
+__global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
+    const u64 *pA, const u64 *pB, int8_t *winner, uint8_t *terminal, u64 *legal,
+    int64_t *key, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_unpack(pA[i], pB[i], s);
+    int w, t;
+    cold_update_winner(s, w, t);
+    winner[i] = (int8_t)w;
+    terminal[i] = (uint8_t)t;
+    legal[i] = cold_legal_mask(s);
+    key[i] = cold_py_hash(s);
+}
+
+// MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
+// re-sampling make_move until the other branch appears.
+__global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
+    const u64 *pA, const u64 *pB, const uint8_t *action36,
+    u64 *c0A, u64 *c0B, u64 *c1A, u64 *c1B, uint8_t *n_children,
+    int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[STEP_LUT_BYTES];
+    fill_step_lut(lut);
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 A = pA[i], B = pB[i];
+    const u32 a = action36[i];
+    const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
+    const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
+    u64 kidA[2], kidB[2];
+#pragma unroll
+    for (u32 bit = 0; bit < 2; ++bit) {
+        u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32);
+        step_core<false>(A0, A1, B0, B1, act, bit, lut);
+        kidA[bit] = (u64)A0 | ((u64)A1 << 32);
+        kidB[bit] = (u64)B0 | ((u64)B1 << 32);
+    }
+    // a move was played iff the nibbles changed (the new edge always writes one); a collapse
+    // happened iff the classical mask changed (mcts.py:245 compares the boards)
+    const bool played = (kidB[0] & 0xFFFFFFFFFull) != (B & 0xFFFFFFFFFull);
+    const u32 cl_before = classical_mask((u32)(A >> 32), (u32)B, (u32)(B >> 32));
+    const u32 cl_after = classical_mask((u32)(kidA[0] >> 32), (u32)kidB[0], (u32)(kidB[0] >> 32));
+    const u32 kids = !played ? 0u : (cl_after != cl_before ? 2u : 1u);
+    n_children[i] = (uint8_t)kids;
+    c0A[i] = kidA[0]; c0B[i] = kidB[0];
+    c1A[i] = kidA[1]; c1B[i] = kidB[1];
+    for (u32 c = 0; c < 2; ++c) {
+        int w = -1, t = 0;
+        u64 lm = 0;
+        int64_t k = 0;
+        if (c < kids) {
+            Cold s;
+            cold_unpack(kidA[c], kidB[c], s);
+            cold_update_winner(s, w, t);
+            lm = cold_legal_mask(s);
+            k = cold_py_hash(s);
+        }
+        winner[i * 2 + c] = (int8_t)w;
+        terminal[i * 2 + c] = (uint8_t)t;
+        legal[i * 2 + c] = lm;
+        key[i * 2 + c] = k;
+    }
+}
+
+// MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
+// random moves to the end with the board in registers.  Ply p uses the counter hash of
+// (seed, board id, step_idx0 + p) exactly like qttt_sample_actions + qttt_step would.
+__global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
+    const u64 *pA, const u64 *pB, u64 seed, u32 step_idx0, u64 board_offset,
+    int8_t *result, uint8_t *plies, u64 *fA, u64 *fB, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[STEP_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    fill_policy_lut(plut);
+    fill_step_lut(lut);                                   // ends with the workgroup barrier
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 A = pA[i], B = pB[i];
+    u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32);
+    const u32 id = fold_id(board_offset + (u64)i);
+    u32 played = 0;
+    for (u32 p = 0; p < 9u; ++p) {
+        const u32 empty = ~classical_mask(A1, B0, B1) & 0x1FFu;
+        if ((A1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
+        const u64 key = launch_key(seed, step_idx0 + p);
+        const u32 h1 = lowbias32(id ^ (u32)key);
+        const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+        step_core<false>(A0, A1, B0, B1, policy_action(plut, empty, h2), h1 >> 31, lut);
+        played += 1u;
+    }
+    const u64 oA = (u64)A0 | ((u64)A1 << 32), oB = (u64)B0 | ((u64)B1 << 32);
+    Cold s;
+    cold_unpack(oA, oB, s);
+    int w, t;
+    cold_update_winner(s, w, t);
+    result[i] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));       // MCTS._reward, mcts.py:200-209
+    plies[i] = (uint8_t)played;
+    if (fA) { fA[i] = oA; fB[i] = oB; }
+}
+
+// GameState.to_vector (mcts.py:67-85) as f32[18][10] and action_mask (mcts.py:87-91).
+// A 256-thread workgroup owns 64 boards: thread (board b, part p) builds the rows of squares
+// p, p+4, p+8 in an LDS tile, then all four waves stream the tile out as fully coalesced 16-byte
+// stores (a lane-per-board store would scatter 16-byte pieces 720 bytes apart; one wave per tile
+// would leave the CU at 3 waves because of the 46 KB tile).
+#define QTTT_ENC_BOARDS 64
+#define QTTT_ENC_BLOCK 256
+__global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
+    const u64 *pA, const u64 *pB, float *vec, uint8_t *mask, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float tile[QTTT_ENC_BOARDS * 180];
+    __shared__ __attribute__((aligned(16))) uint8_t mtile[QTTT_ENC_BOARDS * 36];
+    const int64_t base = (int64_t)blockIdx.x * QTTT_ENC_BOARDS;
+    const u32 b = threadIdx.x & 63u, part = threadIdx.x >> 6;
+    const int64_t i = base + b;
+    const u32 valid = (u32)min((int64_t)QTTT_ENC_BOARDS, n - base);
+    if (b < valid) {
+        Cold s;
+        cold_unpack(pA[i], pB[i], s);
+        float *o = tile + b * 180;
+        const u32 qsets = s.comp(0) | s.comp(1) | s.comp(2) | s.comp(3);
+        for (u32 v = part; v < 9; v += 4) {
+            const u32 col = (s.cl >> v & 1u) ? s.sqv(v) : 9u;        // board -1 indexes column 9
+            u32 touched = 0;                                       // rounds whose move touches v
+            for (u32 t = 0; t < s.n; ++t)
+                if ((s.mv(t) & 0xFu) == v || (s.mv(t) >> 4) == v) touched |= 1u << t;
+            for (u32 c = 0; c < 10; ++c) {
+                o[v * 10 + c] = c == col ? 1.0f : 0.0f;
+                float q = (touched >> c & 1u) ? (1.0f / 3.0f) : 0.0f;   // 1/math.sqrt(9)
+                if (c == 9u && !(qsets >> v & 1u)) q = 1.0f;        // square in no qstruct
+                o[90 + v * 10 + c] = q;
+            }
+        }
+        if (mask && part == 3u) {                                  // the lightest part also does the mask
+            const u64 lm = cold_legal_mask(s);
+            for (int a = 0; a < 36; ++a) mtile[b * 36 + a] = (uint8_t)(lm >> a & 1ull);
+        }
+    }
+    __syncthreads();
+    {
+        const u32 n4 = valid * 45u;                                // float4 pieces in this tile
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(tile);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(vec + base * 180);
+        for (u32 k = threadIdx.x; k < n4; k += QTTT_ENC_BLOCK) __builtin_nontemporal_store(src[k], &dst[k]);
+    }
+    if (mask) {
+        const u32 n4 = valid * 9u;                                 // 4-byte pieces (36 = 9 x 4)
+        const u32 *src = reinterpret_cast<const u32 *>(mtile);
+        u32 *dst = reinterpret_cast<u32 *>(mask + base * 36);
+        for (u32 k = threadIdx.x; k < n4; k += QTTT_ENC_BLOCK) dst[k] = src[k];
+    }
+}
+
+// tuning knob (bench / profiling): boards per lane of the step kernel (1|2|4).  Initialised from
+// QTTT_STEP_BPL, changeable at run time through qttt_set_tuning().
+inline int &tuning_bpl() {
+    static int v = [] {
+        int k = QTTT_DEFAULT_BPL;
+        if (const char *e = getenv("QTTT_STEP_BPL")) { int q = atoi(e); if (q == 1 || q == 2 || q == 4) k = q; }
+        return k;
+    }();
+    return v;
+}
+
+inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
+inline int cold_grid_for(int64_t n) { return (int)((n + QTTT_COLD_BLOCK - 1) / QTTT_COLD_BLOCK); }
+inline int step_grid_for(int64_t n_groups) {
+    return (int)((n_groups + (int64_t)QTTT_BLOCK * QTTT_TPL - 1) / ((int64_t)QTTT_BLOCK * QTTT_TPL));
+}
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int qttt_abi_version(void) { return QTTT_ABI_VERSION; }
+
+#ifdef QTTT_DEBUG_STAMPS
+int qttt_debug_set_stamps(void *buf) {
+    u64 *p = (u64 *)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_debug_stamps), &p, sizeof(p));
+}
+#endif
+
+int qttt_set_tuning(int boards_per_lane, int reserved) {
+    (void)reserved;
+    if (!(boards_per_lane == 1 || boards_per_lane == 2 || boards_per_lane == 4)) return QTTT_ERR_SIZE;
+    tuning_bpl() = boards_per_lane;
+    return 0;
+}
+
+int64_t qttt_state_bytes(int64_t n) { return n < 0 ? (int64_t)QTTT_ERR_SIZE : plane_stride(n) * STATE_BYTES; }
+
+uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx) {
+    const u64 key = launch_key(seed, step_idx);
+    const u32 h1 = lowbias32(fold_id(board_id) ^ (u32)key);
+    const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+    return ((u64)h2 << 32) | h1;
+}
+
+int qttt_reset(void *state, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state) return QTTT_ERR_NULL;
+    // the empty board is the all-zero state
+    hipError_t e = hipMemsetAsync(state, 0, (size_t)(plane_stride(n) * STATE_BYTES), (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                       uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+                       uint8_t *terminated, int64_t n, void *stream, bool sample) {
+    if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !reward || !terminated || (!sample && !actions)) return QTTT_ERR_NULL;
+    if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are accessed as u16 pairs
+    Planes p = planes(state, n);
+    const u64 key = launch_key(seed, step_idx);
+    const u32 key_lo = (u32)key, key_hi = (u32)(key >> 32);
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t *a16 = reinterpret_cast<uint16_t *>(actions);
+    u32 *rb = reinterpret_cast<u32 *>(reward);
+    const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
+    // widest boards-per-lane the caller's pointers are aligned for (the planes always are)
+    int bpl_max = tuning_bpl();
+    auto aligned = [&](int k) {
+        return ((uintptr_t)actions % (2u * k)) == 0 && ((uintptr_t)reward % (4u * k)) == 0 &&
+               ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
+    };
+    while (bpl_max > 1 && !aligned(bpl_max)) bpl_max >>= 1;
+#define QTTT_LAUNCH(BPL, HB, AR, SM, I0, NG, KF, IDB)                                                 \
+    hipLaunchKernelGGL((step_kernel<BPL, HB, AR, SM>), dim3(step_grid_for(NG)), dim3(QTTT_BLOCK), 0, s, \
+                       p.A, p.B, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated,        \
+                       (int64_t)(I0), (int64_t)(NG))
+#define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                                                           \
+    do {                                                                                              \
+        if (sample) { if (ar) QTTT_LAUNCH(BPL, false, true, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, true, I0, NG, KF, IDB); } \
+        else if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, false, I0, NG, KF, IDB); } \
+        else { if (ar) QTTT_LAUNCH(BPL, false, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, false, I0, NG, KF, IDB); } \
+    } while (0)
+    // The hash folds the global board id as lo32 ^ hi32*C (fold_id).  hi32 is uniform over a
+    // range of boards unless the range crosses a multiple of 2^32; the batch is cut there (at most
+    // once), so the kernel only ever adds a lane index to a 32-bit base.
+    int64_t seg_begin = 0;
+    while (seg_begin < n) {
+        const u64 first = (u64)board_offset + (u64)seg_begin;
+        const u64 to_boundary = (((first >> 32) + 1u) << 32) - first;
+        const int64_t seg_n = (int64_t)((u64)(n - seg_begin) < to_boundary ? (u64)(n - seg_begin) : to_boundary);
+        const u32 key_fold = key_lo ^ ((u32)(first >> 32) * 0x9E3779B9u);
+        const u32 id_base = (u32)first;
+        int bpl = bpl_max;
+        while (bpl > 1 && (seg_begin % bpl) != 0) bpl >>= 1;     // vector accesses need an aligned start
+        const int64_t n_groups = seg_n / bpl, n_main = n_groups * bpl;
+        if (n_groups > 0) {
+            if (bpl == 4) QTTT_DISPATCH(4, seg_begin, n_groups, key_fold, id_base);
+            else if (bpl == 2) QTTT_DISPATCH(2, seg_begin, n_groups, key_fold, id_base);
+            else QTTT_DISPATCH(1, seg_begin, n_groups, key_fold, id_base);
+        }
+        if (n_main < seg_n)                                      // ragged tail, one board per lane
+            QTTT_DISPATCH(1, seg_begin + n_main, seg_n - n_main, key_fold, id_base + (u32)n_main);
+        seg_begin += seg_n;
+    }
+#undef QTTT_DISPATCH
+#undef QTTT_LAUNCH
+    return launch_status();
+}
+
+int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+              uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+              uint8_t *terminated, int64_t n, void *stream) {
+    return launch_step(state, const_cast<uint8_t *>(actions), bits, seed, step_idx, board_offset, flags,
+                       reward, terminated, n, stream, false);
+}
+
+int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                     uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
+                     int64_t n, void *stream) {
+    return launch_step(state, actions_out, nullptr, seed, step_idx, board_offset, flags, reward,
+                       terminated, n, stream, true);
+}
+
+int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                   uint32_t step_idx0, int64_t board_offset, uint32_t flags, float *reward,
+                   uint8_t *terminated, int64_t out_stride, int64_t n, int32_t n_steps,
+                   void *stream) {
+    if (n_steps < 0 || out_stride < 0) return QTTT_ERR_SIZE;
+    const u64 first = (u64)(board_offset < 0 ? 0 : board_offset);
+    const bool one_hi = n > 0 && (first >> 32) == ((first + (u64)n - 1u) >> 32);
+    if ((flags & QTTT_FLAG_FUSED) && n > 0 && n_steps > 0 && one_hi) {
+        if (board_offset < 0) return QTTT_ERR_SIZE;
+        if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
+        if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;
+        Planes p = planes(state, n);
+        const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
+        const u32 hi_fold = (u32)(first >> 32) * 0x9E3779B9u;
+        dim3 g(grid_for(n)), b(QTTT_BLOCK);
+        hipStream_t s = (hipStream_t)stream;
+        const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
+        u32 *rb = reinterpret_cast<u32 *>(reward);
+#define QTTT_FUSED(HB, AR)                                                                        \
+    hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.A, p.B, a16, bits, (u64)seed, \
+                       step_idx0, hi_fold, (u32)first, rb, terminated, out_stride, n, n_steps)
+        if (bits) { if (ar) QTTT_FUSED(true, true); else QTTT_FUSED(true, false); }
+        else      { if (ar) QTTT_FUSED(false, true); else QTTT_FUSED(false, false); }
+#undef QTTT_FUSED
+        return launch_status();
+    }
+    for (int32_t t = 0; t < n_steps; ++t) {
+        int rc = qttt_step(state, actions + (int64_t)t * 2 * n, bits ? bits + (int64_t)t * n : nullptr,
+                           seed, step_idx0 + (uint32_t)t, board_offset, flags,
+                           reward + (int64_t)t * out_stride, terminated + (int64_t)t * out_stride,
+                           n, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
+                 uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !classical || !q_p1 || !q_p1_len || !q_p2 || !q_p2_len || !turn) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    hipLaunchKernelGGL(observe_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, classical, q_p1, q_p1_len, q_p2, q_p2_len, turn, n);
+    return launch_status();
+}
+
+int qttt_check_win(const void *state, int8_t *p1_round, int8_t *p2_round, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !p1_round || !p2_round) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    hipLaunchKernelGGL(check_win_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, p1_round, p2_round, n);
+    return launch_status();
+}
+
+int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *board,
+                uint16_t *qmask, uint8_t *n_q, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    hipLaunchKernelGGL(export_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, moves, n_moves, board, qmask, n_q, n);
+    return launch_status();
+}
+
+int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
+                const uint16_t *qmask, const uint8_t *n_q, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
+    Planes p = planes(state, n);
+    hipLaunchKernelGGL(import_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, moves, n_moves, board, qmask, n_q, n);
+    return launch_status();
+}
+
+int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                        uint32_t flags, uint8_t *actions, int64_t n, void *stream) {
+    if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !actions) return QTTT_ERR_NULL;
+    if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // written as u16 pairs
+    Planes p = planes(const_cast<void *>(state), n);
+    const u64 key = launch_key(seed, step_idx);
+    hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0,
+                       (hipStream_t)stream, p.A, p.B, (u32)key, (u32)(key >> 32), (u64)board_offset,
+                       (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), reinterpret_cast<uint16_t *>(actions), n);
+    return launch_status();
+}
+
+int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                   int64_t *key, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !winner || !terminal || !legal || !key) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    hipLaunchKernelGGL(node_info_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, winner, terminal, (u64 *)legal, key, n);
+    return launch_status();
+}
+
+int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *child1,
+                uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                int64_t *key, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !action36 || !child0 || !child1 || !n_children || !winner || !terminal || !legal || !key)
+        return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
+    hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, action36, c0.A, c0.B, c1.A, c1.B, n_children, winner,
+                       terminal, (u64 *)legal, key, n);
+    return launch_status();
+}
+
+int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
+                 int8_t *result, uint8_t *plies, void *final_state, int64_t n, void *stream) {
+    if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !result || !plies) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    Planes f = {nullptr, nullptr};
+    if (final_state) f = planes(final_state, n);
+    hipLaunchKernelGGL(rollout_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.A, p.B, (u64)seed, step_idx0, (u64)board_offset, result, plies, f.A, f.B, n);
+    return launch_status();
+}
+
+int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !vec) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    if (((uintptr_t)vec & 15u) || ((uintptr_t)mask & 3u)) return QTTT_ERR_ACTION;   // vector stores
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + QTTT_ENC_BOARDS - 1) / QTTT_ENC_BOARDS)),
+                       dim3(QTTT_ENC_BLOCK), 0, (hipStream_t)stream, p.A, p.B, vec, mask, n);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -123,7 +123,8 @@ int main(int argc, char **argv) {
         libs.push_back(L);
     }
     void *state; uint8_t *actions, *term; float *reward;
-    CK(hipMalloc(&state, libs[0].state_bytes(n)));
+    const int64_t sb_per_board = libs[0].state_bytes(64) / 64;   // 16 or 20, by build
+    CK(hipMalloc(&state, std::max<int64_t>(libs[0].state_bytes(n), 20 * ((n + 63) & ~63ll))));
     CK(hipMalloc(&actions, (size_t)T * n * 2));
     CK(hipMalloc(&reward, n * 4));
     CK(hipMalloc(&term, n));
@@ -220,10 +221,11 @@ int main(int argc, char **argv) {
         }
     }
     double bytes = 47.0 * n;
+    const double lib_bytes = (2.0 * sb_per_board + 7.0) * n;   // algorithmic bytes of the library's layout
     for (auto &L : libs) {
         std::sort(L.us.begin(), L.us.end());
-        printf("step  %-44s us/launch min %6.2f med %6.2f  %6.1f Gsteps/s %5.0f GB/s\n", L.spec.c_str(), L.us.front(),
-               L.us[L.us.size() / 2], n / L.us.front() * 1e-3, bytes / L.us.front() * 1e-3);
+        printf("step  %-44s us/launch min %6.2f med %6.2f  %6.1f Gsteps/s %5.0f GB/s (%d B state)\n", L.spec.c_str(), L.us.front(),
+               L.us[L.us.size() / 2], n / L.us.front() * 1e-3, lib_bytes / L.us.front() * 1e-3, (int)sb_per_board);
     }
     int vi = 0;
     for (int bplv : {1, 2, 4}) {
