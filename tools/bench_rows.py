@@ -66,6 +66,17 @@ def main():
     t = timed(lambda: env._lib.qttt_encode(env.state.data_ptr(), vec.data_ptr(), mask.data_ptr(), n, s))
     out.append({"row": "encode", "boards": n, "us": t * 1e6, "boards_per_s": n / t,
                 "output_GBps": n * (720 + 36) / t / 1e9})
+    # cold kernels a per-step RL loop calls: observation, Board attributes, check_win
+    n = 1 << 20
+    env = midgame(n, 5)
+    t = timed(lambda: env.observ(), reps=10)
+    out.append({"row": "observe", "boards": n, "us": t * 1e6, "output_bytes_per_board": 30})
+    t = timed(lambda: env.export_boards(), reps=10)
+    out.append({"row": "export", "boards": n, "us": t * 1e6, "output_bytes_per_board": 37})
+    t = timed(lambda: env.check_win(), reps=10)
+    out.append({"row": "check_win", "boards": n, "us": t * 1e6, "output_bytes_per_board": 2})
+    t = timed(lambda: env.node_info(), reps=10)
+    out.append({"row": "node_info", "boards": n, "us": t * 1e6, "output_bytes_per_board": 18})
     # fused replay (QTTT_FLAG_FUSED): T steps per launch, boards in registers
     for n in (4096, 262144, 1 << 20):
         T = 64
