@@ -61,6 +61,13 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
               uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
               uint8_t *terminated, int64_t n, void *stream);
 
+/* Mapping study, not for production: the same step with ONE WAVEFRONT PER BOARD (lane 0 of each
+ * wave runs the board, state staged through LDS), i.e. the floor of any wave-per-board design.
+ * Same arguments and results as qttt_step (one 2^32 id range only).  DESIGN.md §2. */
+int qttt_step_wave_per_board(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                             uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+                             uint8_t *terminated, int64_t n, void *stream);
+
 /* n_steps consecutive qttt_step launches enqueued back to back from C, so a replay / rollout
  * loop is not paced by the host interpreter.  Step t (0-based) reads actions + t*2n and
  * bits + t*n (when bits != NULL), uses step_idx0 + t, and writes reward + t*out_stride and

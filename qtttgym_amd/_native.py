@@ -19,6 +19,7 @@ SIGNATURES = {
     "qttt_state_bytes": (_i64, [_i64]),
     "qttt_reset": (_i32, [_vp, _i64, _vp]),
     "qttt_step": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
+    "qttt_step_wave_per_board": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
     "qttt_step_many": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _i64, _i32, _vp]),
     "qttt_observe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_check_win": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -362,3 +362,23 @@ def test_step_random_equals_policy_then_step(n, auto_reset):
         a_or = ob.sample_actions(seed, t, off, auto_reset)
         ob.step(a_or, None, seed, t, off, auto_reset)
     assert_same_as_oracle(b_env, ob)
+
+
+def test_wave_per_board_study_kernel_gives_the_same_results():
+    """The mapping-study kernel (one wavefront per board) is the same function."""
+    from qtttgym_amd import VecEnv, _native
+    n, seed = 4099, 6
+    ref = VecEnv(n, seed=seed, auto_reset=True)
+    env = VecEnv(n, seed=seed, auto_reset=True)
+    L = _native.lib()
+    r = torch.empty(n, dtype=torch.float32, device="cuda")
+    tm = torch.empty(n, dtype=torch.bool, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for t in range(12):
+        a = ref.sample_actions()
+        r_ref, t_ref = ref.step_raw(a)
+        rc = L.qttt_step_wave_per_board(env.state.data_ptr(), a.data_ptr(), None, seed, t, 0, 1,
+                                        r.data_ptr(), tm.data_ptr(), n, s)
+        assert rc == 0
+        assert torch.equal(r.view(torch.int32), r_ref.view(torch.int32)) and torch.equal(tm, t_ref)
+        assert torch.equal(env.state, ref.state)

@@ -100,6 +100,7 @@ struct Lib {
     int (*step_many)(void *, const uint8_t *, const uint8_t *, uint64_t, uint32_t, int64_t, uint32_t, float *, uint8_t *, int64_t, int64_t, int32_t, void *);
     int (*sample)(const void *, uint64_t, uint32_t, int64_t, uint32_t, uint8_t *, int64_t, void *);
     int (*set_tuning)(int, int);
+    int (*step_wpb)(void *, const uint8_t *, const uint8_t *, uint64_t, uint32_t, int64_t, uint32_t, float *, uint8_t *, int64_t, void *);
     std::vector<float> us;
 };
 
@@ -120,6 +121,7 @@ int main(int argc, char **argv) {
 #define SYM(f, name) *(void **)(&L.f) = dlsym(L.h, name); if (!L.f) { fprintf(stderr, "missing %s\n", name); return 1; }
         SYM(state_bytes, "qttt_state_bytes") SYM(reset, "qttt_reset") SYM(step, "qttt_step")
         SYM(step_many, "qttt_step_many") SYM(sample, "qttt_sample_actions") SYM(set_tuning, "qttt_set_tuning")
+        *(void **)(&L.step_wpb) = dlsym(L.h, "qttt_step_wave_per_board");   // optional
         libs.push_back(L);
     }
     void *state; uint8_t *actions, *term; float *reward;
@@ -219,6 +221,21 @@ int main(int argc, char **argv) {
                        v[n_waves / 2], v[n_waves * 9 / 10], v[n_waves - 1]);
             }
         }
+    }
+    // mapping study: one wavefront per board (a few launches are enough: it is ~50x slower)
+    if (libs[0].step_wpb) {
+        Lib &L = libs[0];
+        L.reset(state, n, s);
+        const int KW = 8;
+        L.step_wpb(state, actions, nullptr, seed, 0, 0, 1, reward, term, n, s);
+        CK(hipEventRecord(e0, s));
+        for (int t = 1; t <= KW; ++t)
+            L.step_wpb(state, actions + (size_t)t * 2 * n, nullptr, seed, t, 0, 1, reward, term, n, s);
+        CK(hipEventRecord(e1, s));
+        CK(hipStreamSynchronize(s));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("wave-per-board study kernel (lane 0 of each wave) %14s us/launch %8.2f  %6.2f Gsteps/s\n", "",
+               ms * 1e3 / KW, n / (ms * 1e3 / KW) * 1e-3);
     }
     double bytes = 47.0 * n;
     const double lib_bytes = (2.0 * sb_per_board + 7.0) * n;   // algorithmic bytes of the library's layout
