@@ -176,34 +176,47 @@ __device__ inline u32 collapse_bit_of(u32 x) {
 }
 
 // ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
-// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4;
-// nth_bit[m][r]: index of the r-th set bit of the 9-bit mask m.  The k-th legal action of a board
-// with empty-square mask m is (nth_bit[m][i], nth_bit[m][j]).
+// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4.
+// nth5[m][r] / nth4[m][r]: index of the r-th set bit of a 5-bit / 4-bit mask: the r-th set bit of the
+// 9-bit empty-square mask is looked up in its low five bits or, past their population, in its
+// high four.  584 bytes in all, so that filling it per workgroup costs next to nothing.
 struct PolicyLut {
     uint8_t rank_pair[10 * 36];
-    uint8_t nth_bit[512 * 9];
-    uint8_t pad[4];
-    constexpr PolicyLut() : rank_pair(), nth_bit(), pad() {
+    uint8_t nth5[32 * 5];
+    uint8_t nth4[16 * 4];
+    constexpr PolicyLut() : rank_pair(), nth5(), nth4() {
         for (int e = 0; e < 10; ++e) {
             int k = 0;
             for (int i = 0; i < e; ++i)
                 for (int j = i + 1; j < e; ++j) rank_pair[e * 36 + k++] = (uint8_t)(i | (j << 4));
             for (; k < 36; ++k) rank_pair[e * 36 + k] = 0;
         }
-        for (int m = 0; m < 512; ++m) {
+        for (int m = 0; m < 32; ++m) {
             int r = 0;
-            for (int v = 0; v < 9; ++v)
-                if (m >> v & 1) nth_bit[m * 9 + r++] = (uint8_t)v;
-            for (; r < 9; ++r) nth_bit[m * 9 + r] = 0;
+            for (int v = 0; v < 5; ++v)
+                if (m >> v & 1) nth5[m * 5 + r++] = (uint8_t)v;
+            for (; r < 5; ++r) nth5[m * 5 + r] = 0;
+        }
+        for (int m = 0; m < 16; ++m) {
+            int r = 0;
+            for (int v = 0; v < 4; ++v)
+                if (m >> v & 1) nth4[m * 4 + r++] = (uint8_t)(5 + v);
+            for (; r < 4; ++r) nth4[m * 4 + r] = 0;
         }
     }
 };
 __constant__ PolicyLut g_policy_lut = PolicyLut();
-constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 512 * 9 + 4) / 4;
+constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 32 * 5 + 16 * 4) / 4;
+constexpr u32 POLICY_NTH5 = 360, POLICY_NTH4 = 360 + 160;
 
 __device__ inline void fill_policy_lut(uint8_t *dst) {
     const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
     for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += QTTT_BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
+}
+
+// the r-th (0-based) set bit of the 9-bit mask `m`
+__device__ __forceinline__ u32 policy_nth(const uint8_t *plut, u32 m, u32 c5, u32 r) {
+    return r < c5 ? (u32)plut[POLICY_NTH5 + (m & 31u) * 5u + r] : (u32)plut[POLICY_NTH4 + (m >> 5) * 4u + (r - c5)];
 }
 
 // the policy's action for a board whose empty-square mask is `empty`, from hash word h2: lo | hi<<8
@@ -211,8 +224,8 @@ __device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32
     const u32 e = (u32)__builtin_popcount(empty);
     const u32 k = __umulhi(h2, (e * (e - 1u)) >> 1);
     const u32 ij = plut[e * 36u + k];
-    const uint8_t *nth = plut + 360u + empty * 9u;
-    return (u32)nth[ij & 0xFu] | ((u32)nth[ij >> 4] << 8);
+    const u32 c5 = (u32)__builtin_popcount(empty & 31u);
+    return policy_nth(plut, empty, c5, ij & 0xFu) | (policy_nth(plut, empty, c5, ij >> 4) << 8);
 }
 
 // ====================================================================== the hot path
