@@ -21,6 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process RCCL on this pool needs dmabuf IPC (the image exports this; keep it if a launcher drops it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 STATE_BYTES = 20          # packed state per board
 ALGO_BYTES_PER_STEP = 2 * STATE_BYTES + 2 + 4 + 1   # state r+w, action, reward f32, terminated
