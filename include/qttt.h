@@ -8,7 +8,7 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and ordered by it;
  *     no call synchronises the device;
  *   - return value: 0 = ok, >0 = hipError_t of the launch, <0 = argument error
- *     (QTTT_ERR_NULL / QTTT_ERR_SIZE / QTTT_ERR_ACTION);
+ *     (QTTT_ERR_NULL / QTTT_ERR_SIZE / QTTT_ERR_ACTION = a pointer not aligned as the entry needs);
  *   - the library is stateless, hence re-entrant;
  *   - illegal *actions* are data, not errors: they are noops exactly as env.py:36-43.
  *
@@ -83,6 +83,7 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
  *   q_p1 u8[n,5,2], q_p1_len u8[n]   un-collapsed even-round moves (lo,hi) in move order, 255 pad
  *   q_p2 u8[n,4,2], q_p2_len u8[n]   un-collapsed odd-round moves
  *   turn u8[n]          len(moves) % 2
+ * Output pointers 4-byte aligned (QTTT_ERR_ACTION otherwise): tiles are written with dword stores.
  */
 int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
                  uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream);

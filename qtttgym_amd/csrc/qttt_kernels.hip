@@ -621,35 +621,61 @@ __device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) 
 
 #define QTTT_COLD_BLOCK 256
 
+// workgroup copy of `nbytes` bytes from an LDS tile to its (4-byte aligned) place in global memory
+__device__ inline void tile_copy_out(uint8_t *dst, const uint8_t *src, u32 nbytes) {
+    const u32 nw = nbytes >> 2;
+    for (u32 k = threadIdx.x; k < nw; k += QTTT_COLD_BLOCK)
+        reinterpret_cast<u32 *>(dst)[k] = reinterpret_cast<const u32 *>(src)[k];
+    for (u32 k = (nw << 2) + threadIdx.x; k < nbytes; k += QTTT_COLD_BLOCK) dst[k] = src[k];
+}
+
+// Env._observation (env.py:68-85).  Each lane unpacks its board into LDS tiles laid out like the
+// outputs, then the workgroup writes every tile with coalesced 4-byte stores (a lane-per-board
+// store would be ~30 single-byte stores per lane, 8..10 bytes apart).
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(
     const u64 *pA, const u64 *pB, const u32 *pC, int8_t *classical, uint8_t *q_p1,
     uint8_t *q_p1_len, uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Cold s;
-    cold_unpack(pA[i], pB[i], pC[i], s);
-    for (u32 v = 0; v < 9; ++v)                                   // env.py:71,82
-        classical[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sqv(v) : (int8_t)-1;
-    u32 n1 = 0, n2 = 0;
-    for (u32 t = 0; t < s.n; ++t) {                               // env.py:72-77
-        const u32 m = s.mv(t);
-        const u32 lo = m & 0xFu, hi = m >> 4;
-        if (s.cl >> lo & 1u) continue;                            // round t is on the board
-        if (t & 1u) {
-            q_p2[i * 8 + n2 * 2] = (uint8_t)lo;
-            q_p2[i * 8 + n2 * 2 + 1] = (uint8_t)hi;
-            ++n2;
-        } else {
-            q_p1[i * 10 + n1 * 2] = (uint8_t)lo;
-            q_p1[i * 10 + n1 * 2 + 1] = (uint8_t)hi;
-            ++n1;
+    __shared__ __attribute__((aligned(16))) uint8_t t_cl[QTTT_COLD_BLOCK * 9];
+    __shared__ __attribute__((aligned(16))) uint8_t t_p1[QTTT_COLD_BLOCK * 10];
+    __shared__ __attribute__((aligned(16))) uint8_t t_p2[QTTT_COLD_BLOCK * 8];
+    __shared__ __attribute__((aligned(16))) uint8_t t_l1[QTTT_COLD_BLOCK], t_l2[QTTT_COLD_BLOCK], t_tn[QTTT_COLD_BLOCK];
+    const int64_t base = (int64_t)blockIdx.x * QTTT_COLD_BLOCK;
+    const int64_t i = base + threadIdx.x;
+    const u32 valid = (u32)min((int64_t)QTTT_COLD_BLOCK, n - base);
+    const u32 b = threadIdx.x;
+    if (b < valid) {
+        Cold s;
+        cold_unpack(pA[i], pB[i], pC[i], s);
+        for (u32 v = 0; v < 9; ++v)                               // env.py:71,82
+            t_cl[b * 9 + v] = (s.cl >> v & 1u) ? (uint8_t)s.sqv(v) : (uint8_t)0xFF;   // -1 as i8
+        u32 n1 = 0, n2 = 0;
+        for (u32 t = 0; t < s.n; ++t) {                           // env.py:72-77
+            const u32 m = s.mv(t);
+            const u32 lo = m & 0xFu, hi = m >> 4;
+            if (s.cl >> lo & 1u) continue;                        // round t is on the board
+            if (t & 1u) {
+                t_p2[b * 8 + n2 * 2] = (uint8_t)lo;
+                t_p2[b * 8 + n2 * 2 + 1] = (uint8_t)hi;
+                ++n2;
+            } else {
+                t_p1[b * 10 + n1 * 2] = (uint8_t)lo;
+                t_p1[b * 10 + n1 * 2 + 1] = (uint8_t)hi;
+                ++n1;
+            }
         }
+        for (u32 k = n1; k < 5; ++k) t_p1[b * 10 + k * 2] = t_p1[b * 10 + k * 2 + 1] = 255;
+        for (u32 k = n2; k < 4; ++k) t_p2[b * 8 + k * 2] = t_p2[b * 8 + k * 2 + 1] = 255;
+        t_l1[b] = (uint8_t)n1;
+        t_l2[b] = (uint8_t)n2;
+        t_tn[b] = (uint8_t)(s.n & 1u);                            // env.py:83
     }
-    for (u32 k = n1; k < 5; ++k) q_p1[i * 10 + k * 2] = q_p1[i * 10 + k * 2 + 1] = 255;
-    for (u32 k = n2; k < 4; ++k) q_p2[i * 8 + k * 2] = q_p2[i * 8 + k * 2 + 1] = 255;
-    q_p1_len[i] = (uint8_t)n1;
-    q_p2_len[i] = (uint8_t)n2;
-    turn[i] = (uint8_t)(s.n & 1u);                                // env.py:83
+    __syncthreads();
+    tile_copy_out(reinterpret_cast<uint8_t *>(classical) + base * 9, t_cl, valid * 9u);
+    tile_copy_out(q_p1 + base * 10, t_p1, valid * 10u);
+    tile_copy_out(q_p2 + base * 8, t_p2, valid * 8u);
+    tile_copy_out(q_p1_len + base, t_l1, valid);
+    tile_copy_out(q_p2_len + base, t_l2, valid);
+    tile_copy_out(turn + base, t_tn, valid);
 }
 
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
@@ -1173,6 +1199,8 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state || !classical || !q_p1 || !q_p1_len || !q_p2 || !q_p2_len || !turn) return QTTT_ERR_NULL;
+    if ((((uintptr_t)classical | (uintptr_t)q_p1 | (uintptr_t)q_p1_len | (uintptr_t)q_p2 |
+          (uintptr_t)q_p2_len | (uintptr_t)turn) & 3u) != 0) return QTTT_ERR_ACTION;   // 4-byte stores
     Planes p = planes(const_cast<void *>(state), n);
     hipLaunchKernelGGL(observe_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.A, p.B, p.C, classical, q_p1, q_p1_len, q_p2, q_p2_len, turn, n);

@@ -70,7 +70,11 @@ def main():
     n = 1 << 20
     env = midgame(n, 5)
     t = timed(lambda: env.observ(), reps=10)
-    out.append({"row": "observe", "boards": n, "us": t * 1e6, "output_bytes_per_board": 30})
+    o = env.observ()
+    t_raw = timed(lambda: env._lib.qttt_observe(env.state.data_ptr(), o["classical"].data_ptr(), o["q_states_p1"].data_ptr(),
+                                                o["q_states_p1_len"].data_ptr(), o["q_states_p2"].data_ptr(),
+                                                o["q_states_p2_len"].data_ptr(), o["turn"].data_ptr(), n, s), reps=20)
+    out.append({"row": "observe", "boards": n, "us": t * 1e6, "us_kernel_only": t_raw * 1e6, "output_bytes_per_board": 30})
     t = timed(lambda: env.export_boards(), reps=10)
     out.append({"row": "export", "boards": n, "us": t * 1e6, "output_bytes_per_board": 37})
     t = timed(lambda: env.check_win(), reps=10)
