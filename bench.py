@@ -1,20 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — vectorised env.step()/s at batch = 1 048 576 boards per MI355X (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--mode replay|gym|policy|random]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one launch of the fused qttt_step kernel over the whole batch of B boards of this
 rank (Env.step for every board, auto-reset throughput mode).  Actions are pre-recorded (an
-untimed pass of policy kernel + step kernel), the boards are reset, and the timed region
-replays the recorded actions, so it contains env.step and nothing else, with inputs resident in
-HBM.  Boards are independent: each rank owns B boards (global ids rank*B..), no data-path
-collective; one RCCL all_reduce of episode counters after the timed region.
+untimed pass of policy kernel + step kernel), the boards are reset, and a timed region replays
+K recorded steps, so it contains env.step and nothing else, with inputs resident in HBM.
+
+Clock.  A region of K launches is short (K = 20 -> 0.16 ms), so the K-launch region is repeated R
+times (R chosen so that the regions add up to >= ~50 ms) and the MEDIAN region is reported.  Each
+region is bracketed by barrier + torch.cuda.synchronize() on both sides and timed twice: by HIP
+events recorded on the launch stream right around the K launches (`value`, `ms_per_step` and
+`roofline` all come from this one clock) and by the host's perf_counter (`host_wall_ms_per_step`,
+reported beside it; it adds the host's launch + synchronise latency, a fixed ~20-60 us per region).
+
+Multi-GPU.  Boards are independent: each rank owns B boards (global ids rank*B..), no data-path
+collective; one RCCL all_reduce of episode counters after the timed regions.  `--gpus N` with no
+WORLD_SIZE in the environment starts its own N ranks (one process per GPU) before anything touches
+the GPU; under torchrun the ranks are taken from the environment.  `ranks_seen` is an all_reduce
+of ones over the process group; the line is refused unless n_gpus == ranks_seen.
+`--boards 262144 --gpus 8` is BASELINE config 4 (2 097 152 boards over 8 GPUs).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,57 +39,127 @@ if ROOT not in sys.path:
 # multi-process RCCL on this pool needs dmabuf IPC (the image exports this; keep it if a launcher drops it)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-STATE_BYTES = 20          # packed state per board
-ALGO_BYTES_PER_STEP = 2 * STATE_BYTES + 2 + 4 + 1   # state r+w, action, reward f32, terminated
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "pmc_traffic.json")
+TARGET_TIMED_S = 0.05     # the repeated regions add up to at least this much device time
+MAX_REGIONS = 400
 
 
-def pmc_traffic_per_launch(boards):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--boards", type=int, default=1 << 20,
+                    help="boards per GPU (262144 with --gpus 8 = BASELINE config 4)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--regions", type=int, default=0, help="repeat count of the K-step timed region (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline")
+    ap.add_argument("--mode", choices=["replay", "gym", "policy", "random"], default="replay",
+                    help="replay: timed region is env.step only (default, the metric); "
+                         "gym: env.step returning the observation too (step + obs fused in one kernel); "
+                         "policy: policy kernel + env.step per step; "
+                         "random: policy and env.step fused in one kernel per step")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------- self-launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks of this script, one per GPU, and exit with
+    the worst of their codes.  The parent never touches the GPU (no torch import here)."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), QTTT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("QTTT_BENCH_TIMEOUT", "1500"))
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is not None:
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+        if rc != 0 or time.time() > deadline:       # one rank failed: the others would hang in a barrier
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------- roofline inputs
+def pmc_traffic_per_launch(boards, state_bytes):
     """HBM bytes per step launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction in
-    MI355X_MICROARCH.md §HBM).  None if no summary for this batch size is committed."""
+    MI355X_MICROARCH.md §HBM).  Not measured in this run: `traffic_source` names the file.
+    None if no summary for this batch size / state layout is committed."""
     try:
-        with open(PMC_SUMMARY) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             d = json.load(f)
-        e = d.get(str(boards))
-        return None if e is None else float(e["hbm_bytes_per_launch"])
+        e = d.get("%d@%dB" % (boards, state_bytes)) or d.get(str(boards))
+        if e is None or int(e.get("state_bytes_per_board", 20)) != state_bytes:
+            return None
+        return float(e["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
 
 
-def cpu_baseline(actions_host, seed, budget_s=12.0):
+def cpu_baseline(actions_host, seed, budget_s):
     """Times the CPU oracle (oracle/qttt_oracle.c, a scalar C port of the reference algorithm)
-    on this box's host cores, on a bounded sample of the same workload: the first recorded steps
-    of a slice of the boards, one slice per thread."""
+    on this box's host cores, on a bounded sample of the same workload: the recorded steps of a
+    slice of the boards, one slice per thread, replayed (reset + replay) until ~budget_s seconds
+    of wall time have been spent on every thread."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     import oracle
     T, n = actions_host.shape[0], actions_host.shape[1]
     cores = max(1, min(os.cpu_count() or 1, 16))   # the GPU box's CPU share for one GPU
     per = n // cores
-    boards = [oracle.OracleBoards(per) for _ in range(cores)]
+    slices = [np.ascontiguousarray(actions_host[:, k * per:(k + 1) * per]) for k in range(cores)]
 
     def work(k):
-        ob = boards[k]
-        lo = k * per
-        done = 0
+        done, passes = 0, 0
         t_end = time.perf_counter() + budget_s
-        for t in range(T):
-            ob.step(np.ascontiguousarray(actions_host[t, lo:lo + per]), None, seed, t, lo, True)
-            done += per
-            if time.perf_counter() > t_end:
-                break
-        return done
+        while True:
+            ob = oracle.OracleBoards(per)            # reset
+            for t in range(T):
+                ob.step(slices[k][t], None, seed, t, k * per, True)
+                done += per
+                if time.perf_counter() > t_end:
+                    return done, passes
+            passes += 1
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(work, range(cores)))
+        res = list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
     py = python_interpreter_line(actions_host, seed)
     return {"value": total / dt, "unit": "steps/s", "cores": cores, "kind": "port",
             "python_interpreter_steps_per_s": py,
-            "sample": "%d boards x %d recorded steps of the same workload (uniform-legal policy, "
-                      "auto-reset), %d threads x %d boards, %.1f s" % (per * cores, total // (per * cores), cores, per, dt)}
+            "sample": "%d boards x the first %d recorded steps of the same workload (uniform-legal policy, "
+                      "auto-reset), replayed from reset %.1f times, %d threads x %d boards, %.1f s of wall time"
+                      % (per * cores, T, total / float(per * cores * T), cores, per, dt)}
 
 
 def python_interpreter_line(actions_host, seed, budget_s=2.0):
@@ -99,32 +184,32 @@ def python_interpreter_line(actions_host, seed, budget_s=2.0):
     return done / (time.perf_counter() - t0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU")
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["replay", "policy", "random"], default="replay",
-                    help="replay: timed region is env.step only (default, the metric); "
-                         "policy: policy kernel + env.step per step; "
-                         "random: policy and env.step fused in one kernel per step")
-    args = ap.parse_args()
+def median(xs):
+    s = sorted(xs)
+    m = len(s) // 2
+    return s[m] if len(s) & 1 else 0.5 * (s[m - 1] + s[m])
 
+
+# ---------------------------------------------------------------------------- one rank
+def run(args):
     import torch
     import torch.distributed as dist
-    from qtttgym_amd import VecEnv
+    from qtttgym_amd import VecEnv, _native
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one rank per GPU; QTTT_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (plumbing only)
     backend = os.environ.get("QTTT_DIST_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("no HIP device visible; bench.py has no CPU path")
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit("--gpus %d needs %d GPUs, %d visible (QTTT_DIST_BACKEND=gloo rehearses several "
+                         "ranks on one GPU)" % (world, world, n_dev))
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -135,9 +220,35 @@ def main():
             dist.init_process_group(backend)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
+    def barrier():
+        if world > 1:
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
+
+    def all_max(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    # how many ranks the process group really has (RCCL's own count, not the environment's)
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones((), dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones)
+
     B, K, W = args.boards, args.steps, args.warmup
     T = K + W
     env = VecEnv(B, device=dev, seed=args.seed, auto_reset=True, board_offset=rank * B)
+    state_bytes = int(_native.lib().qttt_state_bytes(64)) // 64
+    gym = args.mode == "gym"
+    # algorithmic bytes per board-step: state r+w, action, reward f32, terminated (+ the 30-byte
+    # observation of env.py:68-85 in gym mode: classical 9, q_p1 10+1, q_p2 8+1, turn 1)
+    algo_bytes = 2 * state_bytes + 2 + 4 + 1 + (30 if gym else 0)
 
     # ---- untimed: record the action stream of the uniform-legal policy ------------------
     actions = torch.empty((T, B, 2), dtype=torch.uint8, device=dev)
@@ -146,91 +257,131 @@ def main():
     for t in range(T):
         env.sample_actions(out=actions[t])
         r, tm = env.step_raw(actions[t])
-        term_count += tm.sum()
-        win_count += (r != 0).sum()
+        if t >= W:
+            term_count += tm.sum()
+            win_count += (r != 0).sum()
     torch.cuda.synchronize(dev)
     final_state = env.state.clone()
 
-    def barrier():
-        if world > 1:
-            if backend == "nccl":
-                dist.barrier(device_ids=[dev_index])
-            else:
-                dist.barrier()
+    def preroll():
+        """back to the recorded state after W steps (the contract's W untimed warm-up steps)"""
+        env.reset_raw()
+        if W:
+            env.step_many(actions[:W])
 
-    # ---- timed: replay --------------------------------------------------------------
-    env.reset()
-    def one_step():
-        if args.mode == "policy":
-            env.step_raw(env.sample_actions())
+    def timed_steps():
+        if args.mode == "replay":
+            env.step_many(actions[W:])
+        elif gym:
+            for t in range(K):
+                env.step_observe_raw(actions[W + t])
+        elif args.mode == "policy":
+            for t in range(K):
+                env.step_raw(env.sample_actions())
         else:
-            env.step_random()
+            for t in range(K):
+                env.step_random()
 
-    if args.mode == "replay":
-        env.step_many(actions[:W])
-    else:
-        for t in range(W):
-            one_step()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record()
-    if args.mode == "replay":
-        env.step_many(actions[W:])
-    else:
-        for t in range(K):
-            one_step()
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    ev_ms = ev0.elapsed_time(ev1)
+
+    def region():
+        """W untimed steps, then EXACTLY K timed steps between barrier + synchronize pairs."""
+        preroll()
+        torch.cuda.synchronize(dev)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        timed_steps()
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        barrier()
+        return ev0.elapsed_time(ev1) * 1e-3, t1 - t0
+
+    pilot_ev, _ = region()                                   # also the first-touch / clock ramp pass
+    pilot_ev = all_max(pilot_ev)
+    R = args.regions if args.regions > 0 else int(min(MAX_REGIONS, max(5, math.ceil(TARGET_TIMED_S / max(pilot_ev, 1e-6)))))
+    ev_s, wall_s = [], []
+    for _ in range(R):
+        e, w = region()
+        ev_s.append(e)
+        wall_s.append(w)
     replay_ok = bool(torch.equal(env.state, final_state))
+    # MAX over ranks of each rank's median region
+    ev_med, wall_med = all_max(median(ev_s)), all_max(median(wall_s))
+    ev_min = all_max(min(ev_s))
 
     if world > 1:
-        tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, ev_ms = float(tt[0]), float(tt[1])
         # episode counters: the only exchange in the design, once per run, off the timed path
         cnt = torch.stack([term_count, win_count]).to(coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         term_count, win_count = cnt[0], cnt[1]
 
+    rc = 0
     if rank == 0:
-        total_steps = B * K * world
-        value = total_steps / elapsed
-        launch_s = ev_ms * 1e-3 / K
-        achieved = ALGO_BYTES_PER_STEP * B / launch_s / 1e9
-        out = {
-            "metric": "env_steps_per_sec", "value": value, "unit": "steps/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%d boards per GPU, uniform-legal random policy, auto-reset, "
-                                   "%s" % (B, "recorded actions replayed (env.step only in the timed region)"
-                                           if args.mode == "replay" else ("policy kernel + env.step per step" if args.mode == "policy"
-                                                                    else "policy + env.step fused in one kernel per step")),
-                       "boards_per_gpu": B, "state_bytes_per_board": STATE_BYTES,
-                       "parallelism": "shard%d" % world, "mode": args.mode,
-                       "replay_matches_recording": replay_ok,
-                       "episodes_finished": int(term_count), "steps_with_line": int(win_count)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(B),
-                         "kernel": "step_kernel<2,false,true>", "launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * B},
-        }
-        if not args.no_cpu_baseline:
-            # bounded sample: the first <=256 recorded steps of every board of rank 0
-            t_cpu = min(T, 256)
-            out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed)
-        print(json.dumps(out), flush=True)
+        if ranks_seen != args.gpus:
+            print("bench.py: refusing to report n_gpus=%d: the process group has %d ranks" % (args.gpus, ranks_seen),
+                  file=sys.stderr)
+            rc = 3
+        else:
+            launch_s = ev_med / K
+            value = B * K * world / ev_med
+            achieved = algo_bytes * B / launch_s / 1e9
+            bpl = int(os.environ.get("QTTT_STEP_BPL", "2"))
+            kernel = ("step_kernel<%d, false, true, false, %s>" % (bpl, "true" if gym else "false")
+                      if args.mode in ("replay", "gym") else
+                      "step_kernel<%d, false, true, true, false>" % bpl if args.mode == "random" else
+                      "sample_actions_kernel + step_kernel<%d, false, true, false, false>" % bpl)
+            traffic = None if args.mode != "replay" else pmc_traffic_per_launch(B, state_bytes)
+            what = {"replay": "recorded actions replayed (env.step only in the timed region)",
+                    "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel)",
+                    "policy": "policy kernel + env.step per step",
+                    "random": "policy + env.step fused in one kernel per step"}[args.mode]
+            out = {
+                "metric": "env_steps_per_sec", "value": value, "unit": "steps/s", "n_gpus": world,
+                "ranks_seen": ranks_seen, "steps": K, "warmup": W, "ms_per_step": launch_s * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                "data": "synthetic",
+                "clock": "HIP events on the launch stream around the K launches; median of %d regions "
+                         "(max over ranks); value, ms_per_step and roofline all use it" % R,
+                "regions": R, "host_wall_ms_per_step": wall_med * 1e3 / K,
+                "best_region_ms_per_step": ev_min * 1e3 / K,
+                "config": {"workload": "%d boards per GPU, uniform-legal random policy, auto-reset, %s" % (B, what),
+                           "boards_per_gpu": B, "boards_total": B * world, "state_bytes_per_board": state_bytes,
+                           "parallelism": "shard%d" % world, "mode": args.mode,
+                           "dist_backend": backend if world > 1 else None,
+                           "self_launched": bool(os.environ.get("QTTT_BENCH_SELF_LAUNCHED")),
+                           "board_offset_last_rank": (world - 1) * B,
+                           "replay_matches_recording": replay_ok,
+                           "episodes_finished": int(term_count), "steps_with_line": int(win_count)},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                             "traffic_source": None if traffic is None else PMC_SUMMARY,
+                             "kernel": kernel, "launch_us": launch_s * 1e6,
+                             "algorithmic_bytes_per_board_step": algo_bytes,
+                             "algorithmic_bytes_per_launch": algo_bytes * B},
+            }
+            if not args.no_cpu_baseline:
+                # bounded sample: the first <=256 recorded steps of every board of rank 0, ~12 s of CPU
+                t_cpu = min(T, 256)
+                out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed, args.cpu_budget)
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if not replay_ok:
         raise SystemExit("replay diverged from the recording")
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.boards < 1:
+        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # before anything imports torch or touches the GPU
+    sys.exit(run(args))
 
 
 if __name__ == "__main__":

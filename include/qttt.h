@@ -12,9 +12,9 @@
  *   - the library is stateless, hence re-entrant;
  *   - illegal *actions* are data, not errors: they are noops exactly as env.py:36-43.
  *
- * State: an opaque device buffer of qttt_state_bytes(n) bytes for n boards (20 B/board,
- * structure-of-arrays: u64 plane A[s], u64 plane B[s], u32 plane C[s], plane stride
- * s = n rounded up to a multiple of 64).  16-byte aligned at least.
+ * State: an opaque device buffer of qttt_state_bytes(n) bytes for n boards (16 B/board,
+ * structure-of-arrays: u64 plane P[s], u64 plane Q[s], plane stride s = n rounded up to a
+ * multiple of 64).  16-byte aligned at least.
  */
 #ifndef QTTT_H
 #define QTTT_H
@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define QTTT_ABI_VERSION 1
+#define QTTT_ABI_VERSION 2
 
 #define QTTT_ERR_NULL   (-1)
 #define QTTT_ERR_SIZE   (-2)
@@ -61,6 +61,15 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
               uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
               uint8_t *terminated, int64_t n, void *stream);
 
+/* Env.step INCLUDING the observation it returns (env.py:46,53), one fused kernel: qttt_step followed
+ * by qttt_observe, with the observation written from the registers the step holds (no second read
+ * of the state).  Arguments as qttt_step, then as qttt_observe.  q_p1 must be 2-byte and q_p2
+ * 8-byte aligned (QTTT_ERR_ACTION otherwise). */
+int qttt_step_observe(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                      uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+                      uint8_t *terminated, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
+                      uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream);
+
 /* Mapping study, not for production: the same step with ONE WAVEFRONT PER BOARD (lane 0 of each
  * wave runs the board, state staged through LDS), i.e. the floor of any wave-per-board design.
  * Same arguments and results as qttt_step (one 2^32 id range only).  DESIGN.md §2. */
@@ -83,7 +92,7 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
  *   q_p1 u8[n,5,2], q_p1_len u8[n]   un-collapsed even-round moves (lo,hi) in move order, 255 pad
  *   q_p2 u8[n,4,2], q_p2_len u8[n]   un-collapsed odd-round moves
  *   turn u8[n]          len(moves) % 2
- * Output pointers 4-byte aligned (QTTT_ERR_ACTION otherwise): tiles are written with dword stores.
+ * q_p1 must be 2-byte and q_p2 8-byte aligned (QTTT_ERR_ACTION otherwise).
  */
 int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
                  uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # QTTT_LIB_PATH: load another build of the same ABI (A/B diagnostics); default = the in-tree build
 LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FLAG_AUTO_RESET = 1
 FLAG_FUSED = 2
 
@@ -19,6 +19,8 @@ SIGNATURES = {
     "qttt_state_bytes": (_i64, [_i64]),
     "qttt_reset": (_i32, [_vp, _i64, _vp]),
     "qttt_step": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
+    "qttt_step_observe": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _i64, _vp]),
     "qttt_step_wave_per_board": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
     "qttt_step_many": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _i64, _i32, _vp]),
     "qttt_observe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -2,33 +2,44 @@
 //
 // Mapping: ONE LANE PER BOARD (64 boards per wavefront, BPL consecutive boards per lane),
 // everything in VGPRs, structure-of-arrays state so that every load/store of a wave is one
-// contiguous 16-byte-per-lane segment.  No MFMA; LDS holds one 512-byte lookup table.
-// DESIGN.md §2 explains why the wave-per-board mapping was rejected after measurement and why
-// the kernel is written for minimum VALU *instruction count* (measured issue cost ~4 cycles per
-// wave-instruction for this instruction mix, tools/valu_rates.cpp).
+// contiguous 16-byte-per-lane segment.  No MFMA; LDS holds one lookup table (and, in the kernels
+// that return the observation, the output tiles).  DESIGN.md §2 explains why the wave-per-board
+// mapping was rejected after measurement and why the kernel is written for minimum VALU
+// *instruction count* (measured issue cost ~4 cycles per wave-instruction for this instruction mix,
+// tools/valu_rates.cpp).
 //
 // Formulation — deliberately NOT the reference's algorithm:
 //   * the un-collapsed moves of a board form a forest on the 9 squares (a move that closes a
 //     cycle collapses its whole component at once, board.py:42-56).  The forest is kept ROOTED:
 //     nibble sq[v] of a non-classical square v is the round of the move joining v to its parent
-//     (0xF = root / isolated).  For a classical square, sq[v] is the round that landed there
+//     (root / isolated = none).  For a classical square, sq[v] is the round that landed there
 //     (= Board.board[v]).
 //   * QEvalClassic.eval (qeval.py:5-51: leaf-peel + forced walk round the cycle) is equivalent
 //     to: re-root the tree at the square t the closing move lands on (bit picks lo/hi), then
 //     every other square of the component receives its parent edge.  So a collapse is one path
 //     reversal + `classical |= component`; no per-edge work.
+//   * Every move ever played is therefore HELD by exactly one square c (sq[c] = its round): the
+//     child end of an un-collapsed move, the landing square of a collapsed one.  The move itself
+//     is then (c, c ^ x) with x = lo ^ hi, so the state stores only the 4-bit x of each move — the
+//     re-rooting walk needs nothing else ("other end of edge e" = v ^ x_e) and the cold kernels
+//     rebuild Board.moves from the holders.
 //   * Board.qstructs (board.py:6) is cached as 4 slots x 9-bit square masks, in the reference's
 //     list order, so "same component?" is two shifts and an AND.
 //
-// Packed state, 20 B/board, planes A[s] u64 | B[s] u64 | C[s] u32 (s = n rounded up to 64):
-//   A : move queue, newest move in byte 0: the move of round t sits in byte n-1-t
-//       (byte = lo | hi<<4, board.py:19); a 9th entry (only round 0, only when n == 9)
-//       spills into B's `mv8` field.  Unused bytes are 0.
-//   B : bits [0,36) sq nibbles, stored COMPLEMENTED (nibble ^ 0xF, so 0 = root / isolated) |
-//       [36,44) mv8 | [44,48) n = number of moves PLAYED | [48,57) classical mask |
-//       [57,61) comps bits 32..35 | 61,62 zero | 63 done (terminated after the last step)
-//   C : comps bits 0..31   (comps = 4 x 9-bit masks, slot k at bit 9k, list order, compact)
-//   The all-zero state is the empty board, so reset is a memset.
+// Packed state, 16 B/board = 39 algorithmic bytes per step, planes
+// P[s] u64 | Q[s] u64 (s = n rounded up to 64).  The all-zero state is the empty board.
+//   P bits [2,38)  nine nibbles, square v at bits [4v+2, 4v+6), COMPLEMENT-coded: 0 = root /
+//                  isolated / empty, round e is stored as 15-e.  The 2-bit offset makes
+//                  `(P >> 4v) & 0x3C` the code times four, the unit every shift amount below wants.
+//   P1 = P >> 32:  [0,6) nibbles | [6,8) 0 | [8,12) n = moves PLAYED | [12,16) comps bits 32..35 |
+//                  [16,20) x of the last move | [20,22) 0 | [22,31) classical mask | 31 done
+//   Q0:            x = lo^hi of the moves of rounds 0..7: round e in the nibble at bit
+//                  (4(7-e)+2) mod 32, so that rotating Q0 right by four times the CODE of e
+//                  (4(15-e) = 4(7-e) mod 32) lands 4x on bits 2..5.  The move of round 8 can only
+//                  be the last one of a game: its x is the `last x` field of P1 (it is also XORed
+//                  onto round 0's nibble, where it is harmless: the game is over; the cold
+//                  kernels undo it).
+//   Q1:            comps bits 0..31 (comps = 4 x 9-bit masks, slot k at bit 9k, list order, compact)
 //   The autofill of board.py:22-25 is IMPLICIT: a board with exactly 8 classical squares stands
 //   for the reference state in which the 9th square holds round 8 and moves ends with (idx,idx,8)
 //   (the autofill round is always 8); the cold kernels materialise it.
@@ -44,22 +55,19 @@ typedef unsigned int u32;
 #define QTTT_BLOCK 512
 #endif
 #define QTTT_DEFAULT_BPL 2
-#ifndef QTTT_TPL
-#define QTTT_TPL 1      // tiles of QTTT_BLOCK lane-groups per workgroup (each lane: TPL x BPL boards)
-#endif
+#define QTTT_STATE_BYTES 16
 
 namespace {
 
 constexpr u32 SLOT_LSB = 0x08040201u;      // bit 0 of each 9-bit comps slot
 
-// B1 = high word of plane B
-constexpr u32 B1_MV8_SHIFT = 4, B1_N_SHIFT = 12, B1_CL_SHIFT = 16, B1_CHI_SHIFT = 25;
-constexpr u32 B1_DONE = 0x80000000u;
+// P1 = high word of plane P
+constexpr u32 P1_N_SHIFT = 8, P1_CHI_SHIFT = 12, P1_LX_SHIFT = 16, P1_CL_SHIFT = 22;
+constexpr u32 P1_DONE = 0x80000000u;
 
 struct Planes {
-    u64 *A;
-    u64 *B;
-    u32 *C;
+    u64 *P;
+    u64 *Q;
 };
 
 // plane stride: n rounded up to 64 boards, so every plane starts 512-byte aligned
@@ -67,10 +75,8 @@ __host__ __device__ inline int64_t plane_stride(int64_t n) { return (n + 63) & ~
 
 __host__ __device__ inline Planes planes(void *state, int64_t n) {
     Planes p;
-    const int64_t s = plane_stride(n);
-    p.A = reinterpret_cast<u64 *>(state);
-    p.B = p.A + s;
-    p.C = reinterpret_cast<u32 *>(p.B + s);
+    p.P = reinterpret_cast<u64 *>(state);
+    p.Q = p.P + plane_stride(n);
     return p;
 }
 
@@ -83,13 +89,13 @@ struct alignas(sizeof(T) * N) Vec {
 // can be applied to it
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
 template <int BYTES> struct RawOf;
 template <> struct RawOf<1> { typedef uint8_t type; };
 template <> struct RawOf<2> { typedef uint16_t type; };
 template <> struct RawOf<4> { typedef u32 type; };
 template <> struct RawOf<8> { typedef u32x2 type; };
 template <> struct RawOf<16> { typedef u32x4 type; };
-typedef u32 u32x8 __attribute__((ext_vector_type(8)));
 template <> struct RawOf<32> { typedef u32x8 type; };
 
 // Every access of the step kernel is streaming within a launch (each byte is touched once) and L2
@@ -97,27 +103,21 @@ template <> struct RawOf<32> { typedef u32x8 type; };
 // (measured: 8.68 -> 7.96 us per 1 M-board launch)
 template <typename V>
 __device__ __forceinline__ V load_stream(const V *p) {
-#ifndef QTTT_NO_NT
     typedef typename RawOf<sizeof(V)>::type R;
     R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
     V v;
     __builtin_memcpy(&v, &r, sizeof(V));
     return v;
-#else
-    return *p;
-#endif
 }
 template <typename V>
 __device__ __forceinline__ void store_stream(V *p, const V &v) {
-#ifndef QTTT_NO_NT
     typedef typename RawOf<sizeof(V)>::type R;
     R r;
     __builtin_memcpy(&r, &v, sizeof(V));
     __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
-#else
-    *p = v;
-#endif
 }
+
+__device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
 
 #ifdef QTTT_DEBUG_STAMPS
 __device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench stamps)
@@ -125,6 +125,9 @@ __device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/ste
 
 // ------------------------------------------------------------------ 3-in-a-row lookup table
 // line_lut[m] = 0x7F iff the 9-bit square mask m contains one of the 8 lines of board.py:85-110.
+// The LDS copy keeps one entry per DWORD (LINE_LUT_BYTES = 2 KB), because every mask of the hot
+// path lives "times four" (the nibbles sit at bit 4v+2): the byte offset into the table is the
+// mask itself, no shift.
 __host__ __device__ constexpr bool mask_has_line(u32 m) {
     return (m & 0x007u) == 0x007u || (m & 0x038u) == 0x038u || (m & 0x1C0u) == 0x1C0u ||
            (m & 0x049u) == 0x049u || (m & 0x092u) == 0x092u || (m & 0x124u) == 0x124u ||
@@ -138,10 +141,15 @@ struct LineLut {
     }
 };
 __constant__ LineLut g_line_lut = LineLut();
+constexpr u32 LINE_LUT_BYTES = 2048;
 
+template <int BLOCK>
+__device__ inline void fill_line_lut_nosync(uint8_t *lut) {
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = g_line_lut.b[w];
+}
+template <int BLOCK>
 __device__ inline void fill_line_lut(uint8_t *lut) {
-    for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
-        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
+    fill_line_lut_nosync<BLOCK>(lut);
     __syncthreads();
 }
 
@@ -209,9 +217,10 @@ __constant__ PolicyLut g_policy_lut = PolicyLut();
 constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 32 * 5 + 16 * 4) / 4;
 constexpr u32 POLICY_NTH5 = 360, POLICY_NTH4 = 360 + 160;
 
+template <int BLOCK>
 __device__ inline void fill_policy_lut(uint8_t *dst) {
     const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
-    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += QTTT_BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
+    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
 }
 
 // the r-th (0-based) set bit of the 9-bit mask `m`
@@ -229,28 +238,27 @@ __device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32
 }
 
 // ====================================================================== the hot path
-// One Env.step (env.py:34-53) on the board held in (A0,A1,B0,B1,C).  `lut` is the LDS copy of
-// g_line_lut.  Returns 0x7F iff a completed line exists afterwards (else 0); B1's done bit is
-// updated.
+// One Env.step (env.py:34-53) on the board held in (P0,P1,Q0,Q1).  `lut` is the LDS copy of
+// g_line_lut (one entry per dword).  Returns 0x7F iff a completed line exists afterwards (else 0);
+// P1's done bit is updated.
 template <bool AUTO_RESET>
-__device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32 &C, u32 act, u32 bit,
+__device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 act, u32 bit,
                                          const uint8_t *lut) {
     if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
-        const u32 keep = ~(u32)((int)B1 >> 31);         // 0 iff done
-        A0 &= keep;
-        A1 &= keep;
-        B0 &= keep;
-        B1 &= keep;
-        C &= keep;
+        const u32 keep = ~(u32)((int)P1 >> 31);         // 0 iff done
+        P0 &= keep;
+        P1 &= keep;
+        Q0 &= keep;
+        Q1 &= keep;
     }
     const u32 a = act & 0xFFu, b = act >> 8;            // action[0], action[1] (env.py:37-38)
     const u32 lo = min(a, b), hi = max(a, b);           // board.py:16-18
     const u32 pm = (1u << (lo & 31u)) | (1u << (hi & 31u));
-    const u32 cl0 = (B1 >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 cl0 = (P1 >> P1_CL_SHIFT) & 0x1FFu;
     // board.py:10-15 (+ IndexError for >8, swallowed at env.py:41): reject before mutating
     if (hi < 9u && lo != hi && (pm & cl0) == 0u) {
-        const u32 n = (B1 >> B1_N_SHIFT) & 0xFu;
-        u64 comps = (u64)C | ((u64)((B1 >> B1_CHI_SHIFT) & 0xFu) << 32);
+        const u32 n4 = (P1 >> (P1_N_SHIFT - 2u)) & 0x3Cu;            // 4 * moves played (bits 6,7 of P1 are 0)
+        u64 comps = (u64)Q1 | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
         const u32 mlo = (u32)(comps >> lo) & SLOT_LSB;   // slot holding lo (board.py:28-33)
         const u32 mhi = (u32)(comps >> hi) & SLOT_LSB;   // slot holding hi (board.py:35-40)
         const bool has_lo = mlo != 0u, has_hi = mhi != 0u;
@@ -258,35 +266,33 @@ __device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32
         // x: the square that becomes the child end of the new edge; on a cycle it is the square
         // the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi), which becomes the root
         const u32 x4 = ((cyc && bit == 0u) ? lo : hi) * 4u;
-        u64 B = (u64)B0 | ((u64)B1 << 32);               // sq nibbles (complemented) = bits 0..35
+        u64 P = (u64)P0 | ((u64)P1 << 32);
         {   // re-root x's tree at x: reverse the parent edges along the path x -> old root.
-            // XB byte q = (lo^hi)*4 of queue entry q, so "other end of edge e" is one v_perm + xor.
-            // The queue index of round e is n-1-e = ec - (16-n) for the stored ec = e^15; adding ec
-            // to 0x0C0C0C00-(16-n) always carries out of byte 0, leaving selector bytes 1..3 = 0x0C
-            // (constant zero) and byte 0 = the queue index.
-            const u64 A = (u64)A0 | ((u64)A1 << 32);
-            const u64 XB = ((A ^ (A >> 4)) & 0x0F0F0F0F0F0F0F0Full) << 2;
-            const u32 XB0 = (u32)XB, XB1 = (u32)(XB >> 32);
-            const u32 base = 0x0C0C0BF0u + n;
-            // x itself receives this move as its parent edge (complemented round n), every later
-            // node on the path receives the edge its child used to have
-            u32 v4 = x4, prev = 0xFu ^ n;
+            // All quantities are "times four": v4 = 4v is the shift that brings square v's nibble
+            // to bits 2..5, ec4 = 4 * code of the edge found there, and rotating Q0 right by ec4
+            // brings 4 * (lo^hi) of that edge to bits 2..5: the other end of the edge is one
+            // rotate and one xor-and away.
+            // x itself receives this move as its parent edge (code of round n), every later node
+            // on the path receives the edge its child used to have.
+            u32 v4 = x4, prev4 = n4 ^ 0x3Cu;
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
-                const u32 ec = (u32)(B >> v4) & 0xFu;
-                B ^= (u64)(ec ^ prev) << v4;             // sq[v] = prev
-                if (ec == 0u) break;                     // v was the root
-                v4 ^= __builtin_amdgcn_perm(XB1, XB0, base + ec);
-                prev = ec;
+                const u32 t = (u32)(P >> v4);
+                const u32 ec4 = t & 0x3Cu;
+                P ^= (u64)((t ^ prev4) & 0x3Cu) << v4;   // sq[v] = prev
+                if (ec4 == 0u) break;                    // v was the root
+                v4 ^= rotr32(Q0, ec4) & 0x3Cu;
+                prev4 = ec4;
             }
         }
-        B0 = (u32)B;
-        B1 = (u32)(B >> 32);
-        // board.py:19: append to the queue (the byte pushed out of A is 0 unless this is entry 9)
-        B1 |= (A1 >> 20) & 0xFF0u;
-        A1 = (A1 << 8) | (A0 >> 24);
-        A0 = (A0 << 8) | lo | (hi << 4);
-        B1 += 1u << B1_N_SHIFT;
+        P0 = (u32)P;
+        P1 = (u32)(P >> 32);
+        // board.py:19: append.  Only x = lo^hi is kept (see the header): round n <= 7 goes to its
+        // nibble of Q0 (rotate by 4n+4), every move to the `last x` field.
+        const u32 xx4 = (a ^ b) << 2;
+        Q0 ^= rotr32(xx4, n4 + 4u);
+        P1 = (P1 & ~(0xFu << P1_LX_SHIFT)) | (xx4 << (P1_LX_SHIFT - 2u));
+        P1 += 1u << P1_N_SHIFT;
         // ---- board.py:42-69 on the cached qstructs, all three cases in one straight line ----
         const u32 shi = (u32)__builtin_ctz(mhi | 0x80000000u);          // 31 when hi is in no slot
         const u32 c1 = has_hi ? (u32)(comps >> shi) & 0x1FFu : 0u;      // component of hi
@@ -302,42 +308,196 @@ __device__ __forceinline__ u32 step_core(u32 &A0, u32 &A1, u32 &B0, u32 &B1, u32
         const u32 low = ((cyc || uni) ? mhi : 0u) - 1u;                 // all ones = keep everything
         const u32 lowh = (u32)((int)low >> 31);
         const u64 sh9 = comps >> 9;
-        C = ((u32)comps & low) | ((u32)sh9 & ~low);
+        Q1 = ((u32)comps & low) | ((u32)sh9 & ~low);
         const u32 chi = ((u32)(comps >> 32) & lowh) | ((u32)(sh9 >> 32) & ~lowh);
-        B1 = (B1 & ~(0xFu << B1_CHI_SHIFT)) | (chi << B1_CHI_SHIFT);
+        P1 = (P1 & ~(0xFu << P1_CHI_SHIFT)) | (chi << P1_CHI_SHIFT);
         // board.py:44-56 + qeval.py:5-51: on a cycle every square of the component goes classical
         // and already holds its parent edge's round; x holds the closing move's round
-        B1 |= (cyc ? c1 : 0u) << B1_CL_SHIFT;
+        P1 |= (cyc ? c1 : 0u) << P1_CL_SHIFT;
     }
     // board.py:71-115 reduced to "does any line exist" (all that env.py:49,51 need): parity of the
-    // round on each classical square -> X / O masks -> table lookup.  Nibbles are complemented, so
-    // a set low bit means an EVEN round (X).  Eight classical squares = the autofill of
-    // board.py:22-25 is due: the ninth square counts as X (round 8) and the game is over.
-    const u32 par = B0 & 0x11111111u;
-    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
-                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((B1 & 1u) << 8);
-    const u32 cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
-    const u32 pc = (u32)__builtin_popcount(cl);
-    const u32 fill = pc == 8u ? (cl ^ 0x1FFu) : 0u;
-    const u32 win = (u32)lut[(cl & even) | fill] | (u32)lut[cl & ~even];
+    // round on each classical square -> X / O masks -> table lookup.  Codes are complemented, so
+    // a set low bit means an EVEN round (X).  All masks here are "times four" (bit v+2 = square v).
+    // Eight classical squares = the autofill of board.py:22-25 is due: the ninth square counts as
+    // X (round 8) and the game is over.
+    const u32 par4 = P0 & 0x44444444u;
+    const u32 even4 = __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
+                      (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 & 4u) << 8);
+    const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;                // bits 20,21 of P1 are 0
+    const u32 pc = (u32)__builtin_popcount(cl4);
+    const u32 fill4 = pc == 8u ? (cl4 ^ 0x7FCu) : 0u;
+    const u32 win = (u32)lut[(cl4 & even4) | fill4] | (u32)lut[cl4 & ~even4];
     // env.py:51: a line, or len(moves) > 8  <=>  at least 8 classical squares
-    B1 = (B1 & ~B1_DONE) | ((win != 0u || pc >= 8u) ? B1_DONE : 0u);
+    P1 = (P1 & ~P1_DONE) | ((win != 0u || pc >= 8u) ? P1_DONE : 0u);
     return win;
 }
 
+// classical mask the policy sees (a finished board counts as empty under auto-reset)
+template <bool AUTO_RESET>
+__device__ __forceinline__ u32 policy_empty_mask(u32 P1) {
+    const u32 cl = (AUTO_RESET && (P1 >> 31)) ? 0u : (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    return ~cl & 0x1FFu;
+}
+
+// ====================================================================== observation tiles
+// Env._observation (env.py:68-85) is written through LDS tiles laid out exactly like the outputs
+// (row-major per board), so that the workgroup can stream every tile out with coalesced dword
+// stores (a lane-per-board store would be ~30 single-byte stores per lane, 8..10 bytes apart).
+struct ObsOut {                 // global outputs, indexed by the board's local index i
+    int8_t *classical;          // [n,9]
+    uint8_t *q_p1, *q_p1_len;   // [n,5,2], [n]
+    uint8_t *q_p2, *q_p2_len;   // [n,4,2], [n]
+    uint8_t *turn;              // [n]
+};
+struct ObsTiles {               // LDS rows of the workgroup's boards (already phase-shifted)
+    uint8_t *cl, *p1, *p2, *l1, *l2, *tn;
+};
+
+// The tile of an output whose first byte lands at global address g starts at LDS offset (g & 3) of
+// a 16-byte aligned buffer: global and LDS addresses then share their alignment phase and the bulk
+// of the copy is aligned dwords on both sides, whatever board the workgroup starts at.
+__device__ __forceinline__ u32 obs_phase(const void *g) { return (u32)(uintptr_t)g & 3u; }
+
+template <int BLOCK>
+__device__ inline void tile_copy_out(uint8_t *gdst, const uint8_t *tile16, u32 nbytes) {
+    const u32 phase = obs_phase(gdst);
+    const uint8_t *src = tile16 + phase;
+    const u32 head = min((4u - phase) & 3u, nbytes);
+    if (threadIdx.x < head) gdst[threadIdx.x] = src[threadIdx.x];
+    const u32 body = (nbytes - head) >> 2;
+    u32 *gd = reinterpret_cast<u32 *>(gdst + head);
+    const u32 *sd = reinterpret_cast<const u32 *>(src + head);
+    for (u32 k = threadIdx.x; k < body; k += BLOCK) __builtin_nontemporal_store(sd[k], &gd[k]);
+    const u32 k = head + (body << 2) + threadIdx.x;
+    if (k < nbytes) gdst[k] = src[k];
+}
+
+// LDS bytes of the six tiles for `boards` boards (each tile padded for its phase, 16-byte aligned)
+__host__ __device__ constexpr u32 obs_tile_bytes(u32 boards, u32 row) { return (boards * row + 4u + 15u) & ~15u; }
+__host__ __device__ constexpr u32 obs_lds_bytes(u32 boards) {
+    return obs_tile_bytes(boards, 9) + obs_tile_bytes(boards, 10) + obs_tile_bytes(boards, 8) +
+           3u * obs_tile_bytes(boards, 1);
+}
+
+template <u32 BOARDS>
+__device__ __forceinline__ ObsTiles obs_tiles(uint8_t *lds, const ObsOut &o, int64_t first) {
+    ObsTiles t;
+    t.cl = lds + obs_phase(reinterpret_cast<const uint8_t *>(o.classical) + first * 9);
+    lds += obs_tile_bytes(BOARDS, 9);
+    t.p1 = lds + obs_phase(o.q_p1 + first * 10);
+    lds += obs_tile_bytes(BOARDS, 10);
+    t.p2 = lds + obs_phase(o.q_p2 + first * 8);
+    lds += obs_tile_bytes(BOARDS, 8);
+    t.l1 = lds + obs_phase(o.q_p1_len + first);
+    lds += obs_tile_bytes(BOARDS, 1);
+    t.l2 = lds + obs_phase(o.q_p2_len + first);
+    lds += obs_tile_bytes(BOARDS, 1);
+    t.tn = lds + obs_phase(o.turn + first);
+    return t;
+}
+
+template <int BLOCK, u32 BOARDS>
+__device__ inline void obs_copy_out(uint8_t *lds, const ObsOut &o, int64_t first, u32 valid) {
+    tile_copy_out<BLOCK>(reinterpret_cast<uint8_t *>(o.classical) + first * 9, lds, valid * 9u);
+    lds += obs_tile_bytes(BOARDS, 9);
+    tile_copy_out<BLOCK>(o.q_p1 + first * 10, lds, valid * 10u);
+    lds += obs_tile_bytes(BOARDS, 10);
+    tile_copy_out<BLOCK>(o.q_p2 + first * 8, lds, valid * 8u);
+    lds += obs_tile_bytes(BOARDS, 8);
+    tile_copy_out<BLOCK>(o.q_p1_len + first, lds, valid);
+    lds += obs_tile_bytes(BOARDS, 1);
+    tile_copy_out<BLOCK>(o.q_p2_len + first, lds, valid);
+    lds += obs_tile_bytes(BOARDS, 1);
+    tile_copy_out<BLOCK>(o.turn + first, lds, valid);
+}
+
+// The observation of one board, from its packed words, into row b of the tiles.
+//   classical (env.py:71,82): Board.board, -1 for an empty square;
+//   q_states_p1 / p2 (env.py:72-77): (lo,hi) of the un-collapsed moves of even / odd round in move
+//     order, 255-padded.  An un-collapsed move is the parent edge of exactly one non-classical
+//     square c (its holder), and is (c, c ^ x).  Lc collects the codes of the live edges; the place
+//     of an edge in its list is the number of live edges of the same parity with a smaller round
+//     (= a larger code), so every holder writes its pair straight to its final place;
+//   turn (env.py:83): len(moves) % 2, the implicit autofill move included.
+__device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles &T, u32 b) {
+    u64 P = (u64)P0 | ((u64)P1 << 32);
+    u32 cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    const u32 n = (P1 >> P1_N_SHIFT) & 0xFu;
+    const bool fill = __builtin_popcount(cl) == 8;      // the autofill of board.py:22-25 is implicit
+    if (fill) {
+        // the last empty square is isolated (code 0); it holds round n (always 8: SURVEY.md §8a)
+        const u32 idx = (u32)__builtin_ctz(~cl);
+        P |= (u64)(15u - n) << (4u * idx + 2u);
+        cl = 0x1FFu;
+    }
+    // ---- classical: nibbles -> bytes, 15 - code where classical, 0xFF (-1) elsewhere
+    const u32 W = (u32)(P >> 2);
+    const u32 ev = W & 0x0F0F0F0Fu, od = (W >> 4) & 0x0F0F0F0Fu;
+    const u32 c03 = __builtin_amdgcn_perm(od, ev, 0x05010400u);          // codes of squares 0..3
+    const u32 c47 = __builtin_amdgcn_perm(od, ev, 0x07030602u);          // codes of squares 4..7
+    const u32 c8 = (u32)(P >> 34) & 0xFu;
+    const u32 t03 = __umul24(cl & 0xFu, 0x204081u) & 0x01010101u;        // bit v -> byte v
+    const u32 t47 = __umul24((cl >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+    const u32 o03 = (c03 ^ 0x0F0F0F0Fu) | ~((t03 << 8) - t03);
+    const u32 o47 = (c47 ^ 0x0F0F0F0Fu) | ~((t47 << 8) - t47);
+    const u32 o8 = (cl & 0x100u) ? (c8 ^ 0xFu) : 0xFFu;
+    uint8_t *rc = T.cl + b * 9u;
+    rc[0] = (uint8_t)o03;
+    rc[1] = (uint8_t)(o03 >> 8);
+    rc[2] = (uint8_t)(o03 >> 16);
+    rc[3] = (uint8_t)(o03 >> 24);
+    rc[4] = (uint8_t)o47;
+    rc[5] = (uint8_t)(o47 >> 8);
+    rc[6] = (uint8_t)(o47 >> 16);
+    rc[7] = (uint8_t)(o47 >> 24);
+    rc[8] = (uint8_t)o8;
+    // ---- live edges by code: a non-classical square with a parent edge holds code 8..15 (round 7..0)
+    u32 Lc = 0;
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) {
+        const u32 c = (u32)(P >> (4u * v + 2u)) & 0xFu;
+        Lc |= ((cl >> v) & 1u) ? 0u : (1u << c);
+    }
+    Lc &= 0xFF00u;                                        // code 0 = root / isolated
+    uint8_t *r1 = T.p1 + b * 10u, *r2 = T.p2 + b * 8u;
+#pragma unroll
+    for (u32 k = 0; k < 5; ++k) *reinterpret_cast<uint16_t *>(r1 + 2u * k) = (uint16_t)0xFFFFu;
+    *reinterpret_cast<u64 *>(r2) = ~0ull;
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) {
+        const u32 c = (u32)(P >> (4u * v + 2u)) & 0xFu;
+        if (!((cl >> v) & 1u) && c != 0u) {
+            const u32 o = v ^ ((rotr32(Q0, c * 4u) >> 2) & 0xFu);       // the other end of the edge
+            const u32 pair = min(v, o) | (max(v, o) << 8);
+            const u32 odd = c & 1u;                                      // odd code = even round = player 1
+            const u32 rank = (u32)__builtin_popcount(Lc & (0x5500u << odd) & (0xFFFFFFFEu << c));
+            uint8_t *dst = (odd ? r1 : r2) + 2u * rank;
+            *reinterpret_cast<uint16_t *>(dst) = (uint16_t)pair;
+        }
+    }
+    T.l1[b] = (uint8_t)__builtin_popcount(Lc & 0xAA00u);
+    T.l2[b] = (uint8_t)__builtin_popcount(Lc & 0x5500u);
+    T.tn[b] = (uint8_t)((n + (fill ? 1u : 0u)) & 1u);                   // env.py:83
+}
+
+// ====================================================================== the step kernels
 // BPL boards per lane: lane j owns boards [j*BPL, (j+1)*BPL), so every plane is read and written
 // with 16-byte vector accesses that are contiguous across the wave.  Addresses are a block-uniform
 // 64-bit base (scalar unit) plus a 32-bit lane offset.
 // SAMPLE: the action is not read but drawn in the kernel from the uniform-legal policy (and written to
 // `actions` when that is not null) — qttt_sample_actions + qttt_step in one launch.
-template <int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false>
+// OBS: Env.step returns the observation too (env.py:46,53): it is written from the registers the
+// step already holds, through the LDS tiles above — qttt_step + qttt_observe in one launch.
+template <int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
 __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
-    u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
-    uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi,
-    u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
-    int64_t i_begin, int64_t n_groups) {
-    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, uint16_t *__restrict__ actions,
+    const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi, u32 id_base,
+    u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, ObsOut obs, int64_t i_begin,
+    int64_t n_groups) {
+    constexpr u32 TILE_BOARDS = QTTT_BLOCK * BPL;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
+    __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -345,87 +505,66 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     typedef Vec<u32, BPL> V32;
     typedef Vec<uint16_t, BPL> V16;
     typedef Vec<uint8_t, BPL> V8;
-    // a block owns QTTT_TPL consecutive tiles of QTTT_BLOCK lane-groups; lane t owns group t of each
-    const int64_t jb = (int64_t)blockIdx.x * (QTTT_BLOCK * QTTT_TPL);   // first lane-group of the block
+    const int64_t jb = (int64_t)blockIdx.x * QTTT_BLOCK;                // first lane-group of the block
     const int64_t ib = i_begin + jb * BPL;                              // first board of the block
     const int64_t left = n_groups - jb;                                 // lane-groups left from here on
+    const bool active = (int64_t)threadIdx.x < left;
+    const u32 g = active ? threadIdx.x : 0u;                            // idle lanes re-read group 0
     // issue all streaming loads first, fill the lookup table while they are in flight
-    V64 a[QTTT_TPL], b[QTTT_TPL];
-    V32 c[QTTT_TPL];
-    V16 act[QTTT_TPL];
-    V8 bt[QTTT_TPL];
-    u32 g[QTTT_TPL];
-    bool active[QTTT_TPL];
-#pragma unroll
-    for (int q = 0; q < QTTT_TPL; ++q) {
-        const u32 gq = (u32)q * QTTT_BLOCK + threadIdx.x;
-        active[q] = (int64_t)gq < left;
-        g[q] = active[q] ? gq : 0u;                                     // idle lanes re-read group 0
-#ifndef QTTT_PLAIN_STATE_LD
-        a[q] = load_stream(&reinterpret_cast<const V64 *>(pA + ib)[g[q]]);
-        b[q] = load_stream(&reinterpret_cast<const V64 *>(pB + ib)[g[q]]);
-        c[q] = load_stream(&reinterpret_cast<const V32 *>(pC + ib)[g[q]]);
-#else
-        a[q] = reinterpret_cast<const V64 *>(pA + ib)[g[q]];
-        b[q] = reinterpret_cast<const V64 *>(pB + ib)[g[q]];
-        c[q] = reinterpret_cast<const V32 *>(pC + ib)[g[q]];
-#endif
-        if (!SAMPLE) act[q] = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g[q]]);
-        if (HAS_BITS) bt[q] = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g[q]]);
-    }
-    for (u32 w = threadIdx.x; w < 128u; w += QTTT_BLOCK)
-        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
-    if (SAMPLE) fill_policy_lut(plut);
+    V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
+    V64 q = load_stream(&reinterpret_cast<const V64 *>(pQ + ib)[g]);
+    V16 act;
+    V8 bt;
+    if (!SAMPLE) act = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g]);
+    if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
+    fill_line_lut_nosync<QTTT_BLOCK>(lut);
+    if (SAMPLE) fill_policy_lut<QTTT_BLOCK>(plut);
+    ObsTiles T;
+    if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
     __syncthreads();
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st1 = __builtin_amdgcn_s_memrealtime();
 #endif
-#pragma unroll
-    for (int q = 0; q < QTTT_TPL; ++q) {
-        if (!active[q]) continue;
+    if (active) {
         V32 rw;
         V8 tm;
-        const u32 id0 = id_base + ((u32)jb + g[q]) * BPL;               // low 32 bits of the global board id
+        const u32 id0 = id_base + ((u32)jb + g) * BPL;                  // low 32 bits of the global board id
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
-            u32 A0 = (u32)a[q].v[k], A1 = (u32)(a[q].v[k] >> 32);
-            u32 B0 = (u32)b[q].v[k], B1 = (u32)(b[q].v[k] >> 32);
-            u32 C = c[q].v[k];
+            u32 P0 = (u32)p.v[k], P1 = (u32)(p.v[k] >> 32);
+            u32 Q0 = (u32)q.v[k], Q1 = (u32)(q.v[k] >> 32);
             u32 bit, av;
             if (SAMPLE) {
                 // the policy sees the board the step will act on: a finished board counts as empty
                 const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
                 const u32 h2 = lowbias32(h1 ^ key_hi);
-                const u32 cl = (AUTO_RESET && (B1 >> 31)) ? 0u : (B1 >> B1_CL_SHIFT) & 0x1FFu;
-                const u32 empty = ~cl & 0x1FFu;
+                const u32 empty = policy_empty_mask<AUTO_RESET>(P1);
                 av = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
-                act[q].v[k] = (uint16_t)av;
+                act.v[k] = (uint16_t)av;
                 bit = h1 >> 31;
             } else {
-                av = act[q].v[k];
-                if (HAS_BITS) bit = bt[q].v[k] & 1u;
+                av = act.v[k];
+                if (HAS_BITS) bit = bt.v[k] & 1u;
                 else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
             }
-            const u32 win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, av, bit, lut);
-            a[q].v[k] = (u64)A0 | ((u64)A1 << 32);
-            b[q].v[k] = (u64)B0 | ((u64)B1 << 32);
-            c[q].v[k] = C;
+            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
+            p.v[k] = (u64)P0 | ((u64)P1 << 32);
+            q.v[k] = (u64)Q0 | ((u64)Q1 << 32);
             rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f
-            tm.v[k] = (uint8_t)(B1 >> 31);
+            tm.v[k] = (uint8_t)(P1 >> 31);
+            if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k);
         }
-#ifndef QTTT_PLAIN_STATE_ST
-        store_stream(&reinterpret_cast<V64 *>(pA + ib)[g[q]], a[q]);
-        store_stream(&reinterpret_cast<V64 *>(pB + ib)[g[q]], b[q]);
-        store_stream(&reinterpret_cast<V32 *>(pC + ib)[g[q]], c[q]);
-#else
-        reinterpret_cast<V64 *>(pA + ib)[g[q]] = a[q];
-        reinterpret_cast<V64 *>(pB + ib)[g[q]] = b[q];
-        reinterpret_cast<V32 *>(pC + ib)[g[q]] = c[q];
-#endif
-        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g[q]], act[q]);
-        store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g[q]], rw);
-        store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g[q]], tm);
+        store_stream(&reinterpret_cast<V64 *>(pP + ib)[g], p);
+        store_stream(&reinterpret_cast<V64 *>(pQ + ib)[g], q);
+        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g], act);
+        store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g], rw);
+        store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g], tm);
+    }
+    if (OBS) {
+        __syncthreads();
+        const u32 valid = (u32)min((int64_t)QTTT_BLOCK, left) * BPL;
+        obs_copy_out<QTTT_BLOCK, TILE_BOARDS>(otile, obs, ib, valid);
     }
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st2 = __builtin_amdgcn_s_memrealtime();
@@ -447,20 +586,18 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
 // step_kernel (tested); measured beside it in tools/stepbench.
 template <bool HAS_BITS, bool AUTO_RESET>
 __global__ __launch_bounds__(256) void step_wave_per_board_kernel(
-    u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
-    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u32 key_fold,
-    u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
-    __shared__ u64 sA[4], sB[4];
-    __shared__ u32 sC[4], sAct[4], sBit[4];
-    for (u32 w = threadIdx.x; w < 128u; w += 256u)
-        reinterpret_cast<u32 *>(lut)[w] = reinterpret_cast<const u32 *>(g_line_lut.b)[w];
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, const uint16_t *__restrict__ actions,
+    const uint8_t *__restrict__ bits, u32 key_fold, u32 id_base, u32 *__restrict__ reward_bits,
+    uint8_t *__restrict__ terminated, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ u64 sP[4], sQ[4];
+    __shared__ u32 sAct[4], sBit[4];
+    fill_line_lut_nosync<256>(lut);
     const int64_t i0 = (int64_t)blockIdx.x * 4;                   // 4 waves = 4 boards per workgroup
     if (threadIdx.x < 4 && i0 + threadIdx.x < n) {                 // cooperative tile load into LDS
         const int64_t i = i0 + threadIdx.x;
-        sA[threadIdx.x] = pA[i];
-        sB[threadIdx.x] = pB[i];
-        sC[threadIdx.x] = pC[i];
+        sP[threadIdx.x] = pP[i];
+        sQ[threadIdx.x] = pQ[i];
         sAct[threadIdx.x] = actions[i];
         sBit[threadIdx.x] = HAS_BITS ? bits[i] & 1u : collapse_bit_of((id_base + (u32)i) ^ key_fold);
     }
@@ -468,13 +605,12 @@ __global__ __launch_bounds__(256) void step_wave_per_board_kernel(
     const u32 w = threadIdx.x >> 6;
     const int64_t i = i0 + w;
     if (i >= n || (threadIdx.x & 63u) != 0u) return;              // lane 0 of each wave owns the board
-    u32 A0 = (u32)sA[w], A1 = (u32)(sA[w] >> 32), B0 = (u32)sB[w], B1 = (u32)(sB[w] >> 32), C = sC[w];
-    const u32 win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, sAct[w], sBit[w], lut);
-    pA[i] = (u64)A0 | ((u64)A1 << 32);
-    pB[i] = (u64)B0 | ((u64)B1 << 32);
-    pC[i] = C;
+    u32 P0 = (u32)sP[w], P1 = (u32)(sP[w] >> 32), Q0 = (u32)sQ[w], Q1 = (u32)(sQ[w] >> 32);
+    const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, sAct[w], sBit[w], lut);
+    pP[i] = (u64)P0 | ((u64)P1 << 32);
+    pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
     reward_bits[i] = 0x80000000u | (win << 23);
-    terminated[i] = (uint8_t)(B1 >> 31);
+    terminated[i] = (uint8_t)(P1 >> 31);
 }
 
 // T consecutive steps in ONE launch (qttt_step_many with QTTT_FLAG_FUSED): the boards stay in
@@ -484,16 +620,16 @@ __global__ __launch_bounds__(256) void step_wave_per_board_kernel(
 // looks at the state between steps needs the one-launch-per-step form).
 template <bool HAS_BITS, bool AUTO_RESET>
 __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
-    u64 *__restrict__ pA, u64 *__restrict__ pB, u32 *__restrict__ pC,
-    const uint16_t *__restrict__ actions, const uint8_t *__restrict__ bits, u64 seed, u32 step_idx0,
-    u32 id_hi_fold, u32 id_base, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
-    int64_t out_stride, int64_t n, int32_t n_steps) {
-    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
-    fill_line_lut(lut);
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, const uint16_t *__restrict__ actions,
+    const uint8_t *__restrict__ bits, u64 seed, u32 step_idx0, u32 id_hi_fold, u32 id_base,
+    u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, int64_t out_stride, int64_t n,
+    int32_t n_steps) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    fill_line_lut<QTTT_BLOCK>(lut);
     const int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 A = pA[i], B = pB[i];
-    u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32), C = pC[i];
+    const u64 P = pP[i], Q = pQ[i];
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
     const u32 id = id_base + (u32)i;
     u32 win = 0;
     for (int32_t t = 0; t < n_steps; ++t) {
@@ -501,17 +637,16 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
         u32 bit;
         if (HAS_BITS) bit = load_stream(&bits[(int64_t)t * n + i]) & 1u;
         else bit = collapse_bit_of(id ^ ((u32)launch_key(seed, step_idx0 + (u32)t) ^ id_hi_fold));
-        win = step_core<AUTO_RESET>(A0, A1, B0, B1, C, act, bit, lut);
+        win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, act, bit, lut);
         if (out_stride != 0 || t == n_steps - 1) {
             const u32 rwv = 0x80000000u | (win << 23);
-            const uint8_t tmv = (uint8_t)(B1 >> 31);
+            const uint8_t tmv = (uint8_t)(P1 >> 31);
             store_stream(&reward_bits[(int64_t)t * out_stride + i], rwv);
             store_stream(&terminated[(int64_t)t * out_stride + i], tmv);
         }
     }
-    pA[i] = (u64)A0 | ((u64)A1 << 32);
-    pB[i] = (u64)B0 | ((u64)B1 << 32);
-    pC[i] = C;
+    pP[i] = (u64)P0 | ((u64)P1 << 32);
+    pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
 }
 
 // ====================================================================== cold paths
@@ -538,20 +673,33 @@ struct Cold {
     __device__ u32 comp(u32 k) const { return (u32)(comps >> (9u * k)) & 0x1FFu; }
 };
 
-__device__ __forceinline__ void cold_unpack(u64 A, u64 B, u32 C, Cold &s) {
-    const u32 B1 = (u32)(B >> 32);
-    s.n = (B1 >> B1_N_SHIFT) & 0xFu;
-    s.cl = (B1 >> B1_CL_SHIFT) & 0x1FFu;
-    s.done = B1 >> 31;
-    const u32 q8 = (B1 >> B1_MV8_SHIFT) & 0xFFu;                  // queue entry 8
+// x = lo ^ hi of the move of round e (e < n real moves), see the layout notes at the top
+__device__ __forceinline__ u32 cold_move_x(u32 Q0, u32 P1, u32 n_real, u32 e) {
+    const u32 last_x = (P1 >> P1_LX_SHIFT) & 0xFu;
+    if (e >= 8u) return last_x;
+    u32 x = (rotr32(Q0, 4u * (7u - e)) >> 2) & 0xFu;
+    if (e == 0u && n_real == 9u) x ^= last_x;                   // round 8's x was XORed onto round 0's nibble
+    return x;
+}
+
+__device__ __forceinline__ void cold_unpack(u64 P, u64 Q, Cold &s) {
+    const u32 P1 = (u32)(P >> 32), Q0 = (u32)Q;
+    s.n = (P1 >> P1_N_SHIFT) & 0xFu;
+    s.cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    s.done = P1 >> 31;
+    s.sq = ((P >> 2) & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;         // stored complemented
+    s.comps = (Q >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
+    // Board.moves from the holders: the square c with sq[c] = e is one end of the move of round e
+    // (child end if un-collapsed, landing square if collapsed), the other end is c ^ x_e
     s.mvq = 0;
     s.mv8 = 0;
-    for (u32 t = 0; t < s.n; ++t) {
-        const u32 q = s.n - 1u - t;                              // queue index of round t
-        s.set_mv(t, q >= 8u ? q8 : (u32)(A >> ((q & 7u) * 8u)) & 0xFFu);
+    const u32 n_real = s.n;
+    for (u32 c = 0; c < 9; ++c) {
+        const u32 e = s.sqv(c);
+        if (e >= n_real) continue;                               // 0xF = root / isolated / empty
+        const u32 o = c ^ cold_move_x(Q0, P1, n_real, e);
+        s.set_mv(e, min(c, o) | (max(c, o) << 4));
     }
-    s.sq = (B & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;                // stored complemented
-    s.comps = (u64)C | ((u64)((B1 >> B1_CHI_SHIFT) & 0xFu) << 32);
     // materialise the implicit autofill (board.py:22-25): exactly 8 classical squares
     if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {
         const u32 idx = (u32)__builtin_ctz(~s.cl);
@@ -562,7 +710,7 @@ __device__ __forceinline__ void cold_unpack(u64 A, u64 B, u32 C, Cold &s) {
     }
 }
 
-__device__ __forceinline__ void cold_pack(const Cold &in, u64 &A, u64 &B, u32 &C) {
+__device__ __forceinline__ void cold_pack(const Cold &in, u64 &P, u64 &Q) {
     Cold s = in;
     // strip an explicit autofill move (lo == hi, always the last one) back to the implicit form
     if (s.n >= 1u && s.n <= 9u) {
@@ -576,18 +724,17 @@ __device__ __forceinline__ void cold_pack(const Cold &in, u64 &A, u64 &B, u32 &C
             s.n -= 1u;
         }
     }
-    A = 0;
-    u32 q8 = 0;
+    u32 Q0 = 0, last_x = 0;
     for (u32 t = 0; t < s.n && t < 9u; ++t) {
-        const u32 q = s.n - 1u - t;
-        if (q >= 8u) q8 = s.mv(t);
-        else A |= (u64)s.mv(t) << (q * 8u);
+        const u32 m = s.mv(t);
+        last_x = ((m & 0xFu) ^ (m >> 4)) & 0xFu;
+        Q0 ^= rotr32(last_x << 2, 4u * t + 4u);                  // as the step kernel appends it
     }
     const u64 sqc = (s.sq & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;
-    const u32 B1 = (u32)(sqc >> 32) | (q8 << B1_MV8_SHIFT) | (s.n << B1_N_SHIFT) | (s.cl << B1_CL_SHIFT) |
-                   (((u32)(s.comps >> 32) & 0xFu) << B1_CHI_SHIFT) | (s.done ? B1_DONE : 0u);
-    B = (u64)(u32)sqc | ((u64)B1 << 32);
-    C = (u32)s.comps;
+    const u32 P1f = (s.n << P1_N_SHIFT) | (((u32)(s.comps >> 32) & 0xFu) << P1_CHI_SHIFT) |
+                    (last_x << P1_LX_SHIFT) | (s.cl << P1_CL_SHIFT) | (s.done ? P1_DONE : 0u);
+    P = (sqc << 2) | ((u64)P1f << 32);
+    Q = (u64)Q0 | ((u64)(u32)s.comps << 32);
 }
 
 // one line of board.py:85-110: p1/p2 = min over completed lines of the max round in the line
@@ -621,69 +768,28 @@ __device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) 
 
 #define QTTT_COLD_BLOCK 256
 
-// workgroup copy of `nbytes` bytes from an LDS tile to its (4-byte aligned) place in global memory
-__device__ inline void tile_copy_out(uint8_t *dst, const uint8_t *src, u32 nbytes) {
-    const u32 nw = nbytes >> 2;
-    for (u32 k = threadIdx.x; k < nw; k += QTTT_COLD_BLOCK)
-        reinterpret_cast<u32 *>(dst)[k] = reinterpret_cast<const u32 *>(src)[k];
-    for (u32 k = (nw << 2) + threadIdx.x; k < nbytes; k += QTTT_COLD_BLOCK) dst[k] = src[k];
-}
-
-// Env._observation (env.py:68-85).  Each lane unpacks its board into LDS tiles laid out like the
-// outputs, then the workgroup writes every tile with coalesced 4-byte stores (a lane-per-board
-// store would be ~30 single-byte stores per lane, 8..10 bytes apart).
-__global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, int8_t *classical, uint8_t *q_p1,
-    uint8_t *q_p1_len, uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t t_cl[QTTT_COLD_BLOCK * 9];
-    __shared__ __attribute__((aligned(16))) uint8_t t_p1[QTTT_COLD_BLOCK * 10];
-    __shared__ __attribute__((aligned(16))) uint8_t t_p2[QTTT_COLD_BLOCK * 8];
-    __shared__ __attribute__((aligned(16))) uint8_t t_l1[QTTT_COLD_BLOCK], t_l2[QTTT_COLD_BLOCK], t_tn[QTTT_COLD_BLOCK];
+// Env._observation (env.py:68-85) of stored boards: one board per lane through the same LDS tiles
+// and the same obs_board() as the fused step kernel.
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(QTTT_COLD_BLOCK)];
     const int64_t base = (int64_t)blockIdx.x * QTTT_COLD_BLOCK;
     const int64_t i = base + threadIdx.x;
     const u32 valid = (u32)min((int64_t)QTTT_COLD_BLOCK, n - base);
-    const u32 b = threadIdx.x;
-    if (b < valid) {
-        Cold s;
-        cold_unpack(pA[i], pB[i], pC[i], s);
-        for (u32 v = 0; v < 9; ++v)                               // env.py:71,82
-            t_cl[b * 9 + v] = (s.cl >> v & 1u) ? (uint8_t)s.sqv(v) : (uint8_t)0xFF;   // -1 as i8
-        u32 n1 = 0, n2 = 0;
-        for (u32 t = 0; t < s.n; ++t) {                           // env.py:72-77
-            const u32 m = s.mv(t);
-            const u32 lo = m & 0xFu, hi = m >> 4;
-            if (s.cl >> lo & 1u) continue;                        // round t is on the board
-            if (t & 1u) {
-                t_p2[b * 8 + n2 * 2] = (uint8_t)lo;
-                t_p2[b * 8 + n2 * 2 + 1] = (uint8_t)hi;
-                ++n2;
-            } else {
-                t_p1[b * 10 + n1 * 2] = (uint8_t)lo;
-                t_p1[b * 10 + n1 * 2 + 1] = (uint8_t)hi;
-                ++n1;
-            }
-        }
-        for (u32 k = n1; k < 5; ++k) t_p1[b * 10 + k * 2] = t_p1[b * 10 + k * 2 + 1] = 255;
-        for (u32 k = n2; k < 4; ++k) t_p2[b * 8 + k * 2] = t_p2[b * 8 + k * 2 + 1] = 255;
-        t_l1[b] = (uint8_t)n1;
-        t_l2[b] = (uint8_t)n2;
-        t_tn[b] = (uint8_t)(s.n & 1u);                            // env.py:83
+    const ObsTiles T = obs_tiles<QTTT_COLD_BLOCK>(otile, obs, base);
+    if (threadIdx.x < valid) {
+        const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
+        obs_board((u32)P, (u32)(P >> 32), (u32)Q, T, threadIdx.x);
     }
     __syncthreads();
-    tile_copy_out(reinterpret_cast<uint8_t *>(classical) + base * 9, t_cl, valid * 9u);
-    tile_copy_out(q_p1 + base * 10, t_p1, valid * 10u);
-    tile_copy_out(q_p2 + base * 8, t_p2, valid * 8u);
-    tile_copy_out(q_p1_len + base, t_l1, valid);
-    tile_copy_out(q_p2_len + base, t_l2, valid);
-    tile_copy_out(turn + base, t_tn, valid);
+    obs_copy_out<QTTT_COLD_BLOCK, QTTT_COLD_BLOCK>(otile, obs, base, valid);
 }
 
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, int8_t *p1_round, int8_t *p2_round, int64_t n) {
+    const u64 *pP, const u64 *pQ, int8_t *p1_round, int8_t *p2_round, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
-    cold_unpack(pA[i], pB[i], pC[i], s);
+    cold_unpack(pP[i], pQ[i], s);
     int p1, p2;
     cold_check_win(s, p1, p2);
     p1_round[i] = (int8_t)p1;
@@ -691,12 +797,12 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
 }
 
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, uint8_t *moves, uint8_t *n_moves,
+    const u64 *pP, const u64 *pQ, uint8_t *moves, uint8_t *n_moves,
     int8_t *board, uint16_t *qmask, uint8_t *n_q, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
-    cold_unpack(pA[i], pB[i], pC[i], s);
+    cold_unpack(pP[i], pQ[i], s);
     for (u32 t = 0; t < 9; ++t) {
         const bool used = t < s.n;
         const u32 m = s.mv(t);
@@ -717,7 +823,7 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
 // Builds the packed state (incl. the rooted forest) from Board attributes assigned by a caller
 // (mcts.py:11-17,241 assign .board/.moves/.qstructs directly).  Not a hot path.
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
-    u64 *pA, u64 *pB, u32 *pC, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
+    u64 *pP, u64 *pQ, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
     const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -762,25 +868,23 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
     int p1, p2;
     cold_check_win(s, p1, p2);
     s.done = (p1 > 0 || p2 > 0 || s.n > 8u) ? 1u : 0u;
-    u64 A, B;
-    u32 C;
-    cold_pack(s, A, B, C);
-    pA[i] = A;
-    pB[i] = B;
-    pC[i] = C;
+    u64 P, Q;
+    cold_pack(s, P, Q);
+    pP[i] = P;
+    pQ[i] = Q;
 }
 
 // legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
 __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
-    const u64 *pB, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint16_t *actions,
+    const u64 *pP, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint16_t *actions,
     int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    fill_policy_lut(plut);
+    fill_policy_lut<QTTT_BLOCK>(plut);
     __syncthreads();
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u32 B1 = (u32)(pB[i] >> 32);
-    const u32 cl = (auto_reset && (B1 >> 31)) ? 0u : (B1 >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 P1 = (u32)(pP[i] >> 32);
+    const u32 cl = (auto_reset && (P1 >> 31)) ? 0u : (P1 >> P1_CL_SHIFT) & 0x1FFu;
     const u32 empty = ~cl & 0x1FFu;
     const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
     const u32 h2 = lowbias32(h1 ^ key_hi);
@@ -850,12 +954,12 @@ __device__ __forceinline__ int64_t cold_py_hash(const Cold &s) {
 }
 
 __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, int8_t *winner, uint8_t *terminal, u64 *legal,
+    const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
     Cold s;
-    cold_unpack(pA[i], pB[i], pC[i], s);
+    cold_unpack(pP[i], pQ[i], s);
     int w, t;
     cold_update_winner(s, w, t);
     winner[i] = (int8_t)w;
@@ -867,42 +971,39 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
 // MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
 // re-sampling make_move until the other branch appears.
 __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, const uint8_t *action36,
-    u64 *c0A, u64 *c0B, u32 *c0C, u64 *c1A, u64 *c1B, u32 *c1C, uint8_t *n_children,
+    const u64 *pP, const u64 *pQ, const uint8_t *action36,
+    u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, uint8_t *n_children,
     int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
-    fill_line_lut(lut);
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    fill_line_lut<QTTT_BLOCK>(lut);
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 A = pA[i], B = pB[i];
-    const u32 C = pC[i];
+    const u64 P = pP[i], Q = pQ[i];
     const u32 a = action36[i];
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
     const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
-    u64 kidA[2], kidB[2];
-    u32 kidC[2];
+    u64 kidP[2], kidQ[2];
     for (u32 bit = 0; bit < 2; ++bit) {
-        u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32), Cc = C;
-        step_core<false>(A0, A1, B0, B1, Cc, act, bit, lut);
-        kidA[bit] = (u64)A0 | ((u64)A1 << 32);
-        kidB[bit] = (u64)B0 | ((u64)B1 << 32);
-        kidC[bit] = Cc;
+        u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
+        step_core<false>(P0, P1, Q0, Q1, act, bit, lut);
+        kidP[bit] = (u64)P0 | ((u64)P1 << 32);
+        kidQ[bit] = (u64)Q0 | ((u64)Q1 << 32);
     }
-    const u32 n_before = ((u32)(B >> 32) >> B1_N_SHIFT) & 0xFu;
-    const u32 n_after = ((u32)(kidB[0] >> 32) >> B1_N_SHIFT) & 0xFu;
-    const u32 cl_before = ((u32)(B >> 32) >> B1_CL_SHIFT) & 0x1FFu;
-    const u32 cl_after = ((u32)(kidB[0] >> 32) >> B1_CL_SHIFT) & 0x1FFu;
+    const u32 n_before = ((u32)(P >> 32) >> P1_N_SHIFT) & 0xFu;
+    const u32 n_after = ((u32)(kidP[0] >> 32) >> P1_N_SHIFT) & 0xFu;
+    const u32 cl_before = ((u32)(P >> 32) >> P1_CL_SHIFT) & 0x1FFu;
+    const u32 cl_after = ((u32)(kidP[0] >> 32) >> P1_CL_SHIFT) & 0x1FFu;
     const u32 kids = n_after == n_before ? 0u : (cl_after != cl_before ? 2u : 1u);   // mcts.py:245
     n_children[i] = (uint8_t)kids;
-    c0A[i] = kidA[0]; c0B[i] = kidB[0]; c0C[i] = kidC[0];
-    c1A[i] = kidA[1]; c1B[i] = kidB[1]; c1C[i] = kidC[1];
+    c0P[i] = kidP[0]; c0Q[i] = kidQ[0];
+    c1P[i] = kidP[1]; c1Q[i] = kidQ[1];
     for (u32 c = 0; c < 2; ++c) {
         int w = -1, t = 0;
         u64 lm = 0;
         int64_t k = 0;
         if (c < kids) {
             Cold s;
-            cold_unpack(kidA[c], kidB[c], kidC[c], s);
+            cold_unpack(kidP[c], kidQ[c], s);
             cold_update_winner(s, w, t);
             lm = cold_legal_mask(s);
             k = cold_py_hash(s);
@@ -918,35 +1019,35 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
 // random moves to the end with the board in registers.  Ply p uses the counter hash of
 // (seed, board id, step_idx0 + p) exactly like qttt_sample_actions + qttt_step would.
 __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, u64 seed, u32 step_idx0, u64 board_offset,
-    int8_t *result, uint8_t *plies, u64 *fA, u64 *fB, u32 *fC, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t lut[512];
+    const u64 *pP, const u64 *pQ, u64 seed, u32 step_idx0, u64 board_offset,
+    int8_t *result, uint8_t *plies, u64 *fP, u64 *fQ, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    fill_policy_lut(plut);
-    fill_line_lut(lut);                                   // ends with the workgroup barrier
+    fill_policy_lut<QTTT_BLOCK>(plut);
+    fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 A = pA[i], B = pB[i];
-    u32 A0 = (u32)A, A1 = (u32)(A >> 32), B0 = (u32)B, B1 = (u32)(B >> 32), C = pC[i];
+    const u64 P = pP[i], Q = pQ[i];
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
     const u32 id = fold_id(board_offset + (u64)i);
     u32 played = 0;
     for (u32 p = 0; p < 9u; ++p) {
-        const u32 empty = ~(B1 >> B1_CL_SHIFT) & 0x1FFu;
-        if ((B1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
+        const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
+        if ((P1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
         const u64 key = launch_key(seed, step_idx0 + p);
         const u32 h1 = lowbias32(id ^ (u32)key);
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
-        step_core<false>(A0, A1, B0, B1, C, policy_action(plut, empty, h2), h1 >> 31, lut);
+        step_core<false>(P0, P1, Q0, Q1, policy_action(plut, empty, h2), h1 >> 31, lut);
         played += 1u;
     }
-    const u64 oA = (u64)A0 | ((u64)A1 << 32), oB = (u64)B0 | ((u64)B1 << 32);
+    const u64 oP = (u64)P0 | ((u64)P1 << 32), oQ = (u64)Q0 | ((u64)Q1 << 32);
     Cold s;
-    cold_unpack(oA, oB, C, s);
+    cold_unpack(oP, oQ, s);
     int w, t;
     cold_update_winner(s, w, t);
     result[i] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));       // MCTS._reward, mcts.py:200-209
     plies[i] = (uint8_t)played;
-    if (fA) { fA[i] = oA; fB[i] = oB; fC[i] = C; }
+    if (fP) { fP[i] = oP; fQ[i] = oQ; }
 }
 
 // GameState.to_vector (mcts.py:67-85) as f32[18][10] and action_mask (mcts.py:87-91).
@@ -957,7 +1058,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
 #define QTTT_ENC_BOARDS 64
 #define QTTT_ENC_BLOCK 256
 __global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
-    const u64 *pA, const u64 *pB, const u32 *pC, float *vec, uint8_t *mask, int64_t n) {
+    const u64 *pP, const u64 *pQ, float *vec, uint8_t *mask, int64_t n) {
     __shared__ __attribute__((aligned(16))) float tile[QTTT_ENC_BOARDS * 180];
     __shared__ __attribute__((aligned(16))) uint8_t mtile[QTTT_ENC_BOARDS * 36];
     const int64_t base = (int64_t)blockIdx.x * QTTT_ENC_BOARDS;
@@ -966,7 +1067,7 @@ __global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
     const u32 valid = (u32)min((int64_t)QTTT_ENC_BOARDS, n - base);
     if (b < valid) {
         Cold s;
-        cold_unpack(pA[i], pB[i], pC[i], s);
+        cold_unpack(pP[i], pQ[i], s);
         float *o = tile + b * 180;
         const u32 qsets = s.comp(0) | s.comp(1) | s.comp(2) | s.comp(3);
         for (u32 v = part; v < 9; v += 4) {
@@ -1014,9 +1115,7 @@ inline int &tuning_bpl() {
 
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
 inline int cold_grid_for(int64_t n) { return (int)((n + QTTT_COLD_BLOCK - 1) / QTTT_COLD_BLOCK); }
-inline int step_grid_for(int64_t n_groups) {
-    return (int)((n_groups + (int64_t)QTTT_BLOCK * QTTT_TPL - 1) / ((int64_t)QTTT_BLOCK * QTTT_TPL));
-}
+inline int step_grid_for(int64_t n_groups) { return (int)((n_groups + QTTT_BLOCK - 1) / QTTT_BLOCK); }
 
 inline int launch_status() {
     hipError_t e = hipGetLastError();
@@ -1044,7 +1143,7 @@ int qttt_set_tuning(int boards_per_lane, int reserved) {
     return 0;
 }
 
-int64_t qttt_state_bytes(int64_t n) { return n < 0 ? (int64_t)QTTT_ERR_SIZE : plane_stride(n) * 20; }
+int64_t qttt_state_bytes(int64_t n) { return n < 0 ? (int64_t)QTTT_ERR_SIZE : plane_stride(n) * QTTT_STATE_BYTES; }
 
 uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx) {
     const u64 key = launch_key(seed, step_idx);
@@ -1058,13 +1157,13 @@ int qttt_reset(void *state, int64_t n, void *stream) {
     if (n == 0) return 0;
     if (!state) return QTTT_ERR_NULL;
     // the empty board is the all-zero state
-    hipError_t e = hipMemsetAsync(state, 0, (size_t)(plane_stride(n) * 20), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(state, 0, (size_t)(plane_stride(n) * QTTT_STATE_BYTES), (hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
 }
 
 static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint64_t seed,
                        uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
-                       uint8_t *terminated, int64_t n, void *stream, bool sample) {
+                       uint8_t *terminated, int64_t n, void *stream, bool sample, const ObsOut *obs) {
     if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state || !reward || !terminated || (!sample && !actions)) return QTTT_ERR_NULL;
@@ -1077,21 +1176,26 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     u32 *rb = reinterpret_cast<u32 *>(reward);
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
     // widest boards-per-lane the caller's pointers are aligned for (the planes always are)
-    int bpl_max = tuning_bpl();
+    int bpl_max = obs ? (tuning_bpl() > 2 ? 2 : tuning_bpl()) : tuning_bpl();   // the tiles are sized for <= 2
     auto aligned = [&](int k) {
         return ((uintptr_t)actions % (2u * k)) == 0 && ((uintptr_t)reward % (4u * k)) == 0 &&
                ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
     };
     while (bpl_max > 1 && !aligned(bpl_max)) bpl_max >>= 1;
-#define QTTT_LAUNCH(BPL, HB, AR, SM, I0, NG, KF, IDB)                                                 \
-    hipLaunchKernelGGL((step_kernel<BPL, HB, AR, SM>), dim3(step_grid_for(NG)), dim3(QTTT_BLOCK), 0, s, \
-                       p.A, p.B, p.C, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated,        \
+    const ObsOut oo = obs ? *obs : ObsOut{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#define QTTT_LAUNCH(BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                              \
+    hipLaunchKernelGGL((step_kernel<BPL, HB, AR, SM, OB>), dim3(step_grid_for(NG)), dim3(QTTT_BLOCK), 0, s, \
+                       p.P, p.Q, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated, oo,         \
                        (int64_t)(I0), (int64_t)(NG))
 #define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                                                           \
     do {                                                                                              \
-        if (sample) { if (ar) QTTT_LAUNCH(BPL, false, true, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, true, I0, NG, KF, IDB); } \
-        else if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, false, I0, NG, KF, IDB); } \
-        else { if (ar) QTTT_LAUNCH(BPL, false, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, false, I0, NG, KF, IDB); } \
+        if (obs) {                                                                                    \
+            if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, false, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, false, true, I0, NG, KF, IDB); } \
+            else { if (ar) QTTT_LAUNCH(BPL, false, true, false, true, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, false, true, I0, NG, KF, IDB); } \
+        }                                                                                             \
+        else if (sample) { if (ar) QTTT_LAUNCH(BPL, false, true, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, true, false, I0, NG, KF, IDB); } \
+        else if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, false, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, false, false, I0, NG, KF, IDB); } \
+        else { if (ar) QTTT_LAUNCH(BPL, false, true, false, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, false, false, I0, NG, KF, IDB); } \
     } while (0)
     // The hash folds the global board id as lo32 ^ hi32*C (fold_id).  hi32 is uniform over a
     // range of boards unless the range crosses a multiple of 2^32; the batch is cut there (at most
@@ -1124,7 +1228,18 @@ int qttt_step(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t
               uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
               uint8_t *terminated, int64_t n, void *stream) {
     return launch_step(state, const_cast<uint8_t *>(actions), bits, seed, step_idx, board_offset, flags,
-                       reward, terminated, n, stream, false);
+                       reward, terminated, n, stream, false, nullptr);
+}
+
+int qttt_step_observe(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
+                      uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
+                      uint8_t *terminated, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
+                      uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream) {
+    if (n > 0 && (!classical || !q_p1 || !q_p1_len || !q_p2 || !q_p2_len || !turn)) return QTTT_ERR_NULL;
+    if (((uintptr_t)q_p1 & 1u) || ((uintptr_t)q_p2 & 7u)) return QTTT_ERR_ACTION;   // 2- / 8-byte LDS row stores
+    const ObsOut o = {classical, q_p1, q_p1_len, q_p2, q_p2_len, turn};
+    return launch_step(state, const_cast<uint8_t *>(actions), bits, seed, step_idx, board_offset, flags,
+                       reward, terminated, n, stream, false, &o);
 }
 
 int qttt_step_wave_per_board(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
@@ -1143,7 +1258,7 @@ int qttt_step_wave_per_board(void *state, const uint8_t *actions, const uint8_t 
     hipStream_t s = (hipStream_t)stream;
     const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
     u32 *rb = reinterpret_cast<u32 *>(reward);
-#define QTTT_WPB(HB, AR) hipLaunchKernelGGL((step_wave_per_board_kernel<HB, AR>), g, b, 0, s, p.A, p.B, p.C, \
+#define QTTT_WPB(HB, AR) hipLaunchKernelGGL((step_wave_per_board_kernel<HB, AR>), g, b, 0, s, p.P, p.Q, \
                                             a16, bits, key_fold, (u32)first, rb, terminated, n)
     if (bits) { if (ar) QTTT_WPB(true, true); else QTTT_WPB(true, false); }
     else      { if (ar) QTTT_WPB(false, true); else QTTT_WPB(false, false); }
@@ -1155,7 +1270,7 @@ int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t boar
                      uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
                      int64_t n, void *stream) {
     return launch_step(state, actions_out, nullptr, seed, step_idx, board_offset, flags, reward,
-                       terminated, n, stream, true);
+                       terminated, n, stream, true, nullptr);
 }
 
 int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
@@ -1177,7 +1292,7 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
         const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
         u32 *rb = reinterpret_cast<u32 *>(reward);
 #define QTTT_FUSED(HB, AR)                                                                        \
-    hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.A, p.B, p.C, a16, bits, (u64)seed, \
+    hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.P, p.Q, a16, bits, (u64)seed, \
                        step_idx0, hi_fold, (u32)first, rb, terminated, out_stride, n, n_steps)
         if (bits) { if (ar) QTTT_FUSED(true, true); else QTTT_FUSED(true, false); }
         else      { if (ar) QTTT_FUSED(false, true); else QTTT_FUSED(false, false); }
@@ -1199,11 +1314,11 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state || !classical || !q_p1 || !q_p1_len || !q_p2 || !q_p2_len || !turn) return QTTT_ERR_NULL;
-    if ((((uintptr_t)classical | (uintptr_t)q_p1 | (uintptr_t)q_p1_len | (uintptr_t)q_p2 |
-          (uintptr_t)q_p2_len | (uintptr_t)turn) & 3u) != 0) return QTTT_ERR_ACTION;   // 4-byte stores
+    if (((uintptr_t)q_p1 & 1u) || ((uintptr_t)q_p2 & 7u)) return QTTT_ERR_ACTION;   // 2- / 8-byte LDS row stores
     Planes p = planes(const_cast<void *>(state), n);
+    const ObsOut o = {classical, q_p1, q_p1_len, q_p2, q_p2_len, turn};
     hipLaunchKernelGGL(observe_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, classical, q_p1, q_p1_len, q_p2, q_p2_len, turn, n);
+                       p.P, p.Q, o, n);
     return launch_status();
 }
 
@@ -1213,7 +1328,7 @@ int qttt_check_win(const void *state, int8_t *p1_round, int8_t *p2_round, int64_
     if (!state || !p1_round || !p2_round) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
     hipLaunchKernelGGL(check_win_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, p1_round, p2_round, n);
+                       p.P, p.Q, p1_round, p2_round, n);
     return launch_status();
 }
 
@@ -1224,7 +1339,7 @@ int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *boa
     if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
     hipLaunchKernelGGL(export_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, moves, n_moves, board, qmask, n_q, n);
+                       p.P, p.Q, moves, n_moves, board, qmask, n_q, n);
     return launch_status();
 }
 
@@ -1235,7 +1350,7 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
     if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
     Planes p = planes(state, n);
     hipLaunchKernelGGL(import_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, moves, n_moves, board, qmask, n_q, n);
+                       p.P, p.Q, moves, n_moves, board, qmask, n_q, n);
     return launch_status();
 }
 
@@ -1248,7 +1363,7 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int
     Planes p = planes(const_cast<void *>(state), n);
     const u64 key = launch_key(seed, step_idx);
     hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0,
-                       (hipStream_t)stream, p.B, (u32)key, (u32)(key >> 32), (u64)board_offset,
+                       (hipStream_t)stream, p.P, (u32)key, (u32)(key >> 32), (u64)board_offset,
                        (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), reinterpret_cast<uint16_t *>(actions), n);
     return launch_status();
 }
@@ -1260,7 +1375,7 @@ int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_
     if (!state || !winner || !terminal || !legal || !key) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
     hipLaunchKernelGGL(node_info_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, winner, terminal, (u64 *)legal, key, n);
+                       p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
     return launch_status();
 }
 
@@ -1273,7 +1388,7 @@ int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *
         return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
     hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, action36, c0.A, c0.B, c0.C, c1.A, c1.B, c1.C, n_children, winner,
+                       p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner,
                        terminal, (u64 *)legal, key, n);
     return launch_status();
 }
@@ -1284,10 +1399,10 @@ int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t b
     if (n == 0) return 0;
     if (!state || !result || !plies) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    Planes f = {nullptr, nullptr, nullptr};
+    Planes f = {nullptr, nullptr};
     if (final_state) f = planes(final_state, n);
     hipLaunchKernelGGL(rollout_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
-                       p.A, p.B, p.C, (u64)seed, step_idx0, (u64)board_offset, result, plies, f.A, f.B, f.C, n);
+                       p.P, p.Q, (u64)seed, step_idx0, (u64)board_offset, result, plies, f.P, f.Q, n);
     return launch_status();
 }
 
@@ -1298,7 +1413,7 @@ int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *s
     Planes p = planes(const_cast<void *>(state), n);
     if (((uintptr_t)vec & 15u) || ((uintptr_t)mask & 3u)) return QTTT_ERR_ACTION;   // vector stores
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + QTTT_ENC_BOARDS - 1) / QTTT_ENC_BOARDS)),
-                       dim3(QTTT_ENC_BLOCK), 0, (hipStream_t)stream, p.A, p.B, p.C, vec, mask, n);
+                       dim3(QTTT_ENC_BLOCK), 0, (hipStream_t)stream, p.P, p.Q, vec, mask, n);
     return launch_status();
 }
 

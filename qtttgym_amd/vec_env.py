@@ -40,6 +40,7 @@ class VecEnv:
             self._reward = torch.empty(n, dtype=torch.float32, device=self.device)
             self._terminated = torch.empty(n, dtype=torch.bool, device=self.device)
             self._truncated = torch.zeros(n, dtype=torch.bool, device=self.device)  # env.py:52
+        self._obs = None
         self.reset()
 
     # ------------------------------------------------------------------ helpers
@@ -62,15 +63,19 @@ class VecEnv:
         return actions.to(self.device).contiguous()
 
     # ------------------------------------------------------------------ gym surface
-    def reset(self, *, seed=None, options=None):
-        """env.py:55-57: fresh boards; `seed`/`options` accepted and ignored like the reference,
-        except that an int `seed` re-keys the collapse-bit hash (the reference has no per-env RNG)."""
+    def reset_raw(self, seed=None):
+        """Fresh boards without building the observation (one memset on the stream)."""
         if seed is not None:
             self.seed = int(seed)
         self.step_idx = 0
         with torch.cuda.device(self.device):
             _native.check(self._lib.qttt_reset(self.state.data_ptr(), self.num_envs, self._stream()),
                           "qttt_reset")
+
+    def reset(self, *, seed=None, options=None):
+        """env.py:55-57: fresh boards; `seed`/`options` accepted and ignored like the reference,
+        except that an int `seed` re-keys the collapse-bit hash (the reference has no per-env RNG)."""
+        self.reset_raw(seed)
         return self.observ(), {}
 
     def step_raw(self, actions, bits=None):
@@ -142,27 +147,61 @@ class VecEnv:
         return r, tm
 
     def step(self, actions, bits=None, verbose=False):
-        """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info)."""
+        """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info) from ONE kernel
+        launch (the step kernel writes the observation from the registers it holds).  The returned
+        tensors are the environment's own buffers, overwritten by the next step()/observ()."""
         actions = self._as_actions(actions)
         if bits is not None:
             bits = torch.as_tensor(bits).to(torch.uint8).to(self.device).contiguous()
-        reward, terminated = self.step_raw(actions, bits)
-        return self.observ(), reward, terminated, self._truncated, {}
+        obs, reward, terminated = self.step_observe_raw(actions, bits)
+        return obs, reward, terminated, self._truncated, {}
+
+    def _obs_buffers(self):
+        """The observation tensors (env.py:19-25,68-85), allocated once per environment."""
+        if self._obs is None:
+            n, dev = self.num_envs, self.device
+            with torch.cuda.device(dev):
+                self._obs = {
+                    "q_states_p1": torch.empty((n, 5, 2), dtype=torch.uint8, device=dev),
+                    "q_states_p1_len": torch.empty(n, dtype=torch.uint8, device=dev),
+                    "q_states_p2": torch.empty((n, 4, 2), dtype=torch.uint8, device=dev),
+                    "q_states_p2_len": torch.empty(n, dtype=torch.uint8, device=dev),
+                    "classical": torch.empty((n, 9), dtype=torch.int8, device=dev),
+                    "turn": torch.empty(n, dtype=torch.uint8, device=dev),
+                }
+        return self._obs
+
+    def step_observe_raw(self, actions, bits=None):
+        """Env.step for N boards including the observation (env.py:46), one fused kernel:
+        qttt_step_observe.  Same argument rules as step_raw.  Returns (obs dict, reward, terminated),
+        all buffers owned by the environment and reused across calls."""
+        n = self.num_envs
+        if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.state.device \
+                or actions.numel() != 2 * n:
+            raise ValueError("step_observe_raw wants a contiguous uint8 device tensor of shape (N, 2)")
+        if bits is not None and (bits.dtype != torch.uint8 or not bits.is_contiguous()
+                                 or bits.device != self.state.device or bits.numel() != n):
+            raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
+        o = self._obs_buffers()
+        with torch.cuda.device(self.device):
+            rc = self._lib.qttt_step_observe(self.state.data_ptr(), actions.data_ptr(), _ptr(bits), self.seed,
+                                             self.step_idx, self.board_offset, self._flags(),
+                                             self._reward.data_ptr(), self._terminated.data_ptr(),
+                                             o["classical"].data_ptr(), o["q_states_p1"].data_ptr(),
+                                             o["q_states_p1_len"].data_ptr(), o["q_states_p2"].data_ptr(),
+                                             o["q_states_p2_len"].data_ptr(), o["turn"].data_ptr(), n,
+                                             self._stream())
+        _native.check(rc, "qttt_step_observe")
+        self.step_idx += 1
+        return o, self._reward, self._terminated
 
     def observ(self):
         """env.py:62-63,68-85 as tensors: q_states_p{1,2} u8[N,5|4,2] (255 pad) with *_len,
-        classical i8[N,9], turn u8[N]."""
+        classical i8[N,9], turn u8[N].  The tensors are the environment's own buffers (allocated
+        once), overwritten by the next observ()/step()."""
         n = self.num_envs
-        dev = self.device
-        with torch.cuda.device(dev):
-            obs = {
-                "q_states_p1": torch.empty((n, 5, 2), dtype=torch.uint8, device=dev),
-                "q_states_p1_len": torch.empty(n, dtype=torch.uint8, device=dev),
-                "q_states_p2": torch.empty((n, 4, 2), dtype=torch.uint8, device=dev),
-                "q_states_p2_len": torch.empty(n, dtype=torch.uint8, device=dev),
-                "classical": torch.empty((n, 9), dtype=torch.int8, device=dev),
-                "turn": torch.empty(n, dtype=torch.uint8, device=dev),
-            }
+        obs = self._obs_buffers()
+        with torch.cuda.device(self.device):
             rc = self._lib.qttt_observe(self.state.data_ptr(), obs["classical"].data_ptr(),
                                         obs["q_states_p1"].data_ptr(), obs["q_states_p1_len"].data_ptr(),
                                         obs["q_states_p2"].data_ptr(), obs["q_states_p2_len"].data_ptr(),
@@ -257,6 +296,7 @@ class VecEnv:
             env._reward = torch.empty(n, dtype=torch.float32, device=env.device)
             env._terminated = torch.empty(n, dtype=torch.bool, device=env.device)
             env._truncated = torch.zeros(n, dtype=torch.bool, device=env.device)
+        env._obs = None
         return env
 
     def node_info(self):

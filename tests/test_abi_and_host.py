@@ -33,7 +33,7 @@ def test_state_bytes_and_hash_are_host_callable():
     import oracle
     L = _native.lib()
     assert L.qttt_state_bytes(0) == 0
-    assert L.qttt_state_bytes(1 << 20) == 20 * (1 << 20)
+    assert L.qttt_state_bytes(1 << 20) == 16 * (1 << 20)
     assert L.qttt_state_bytes(-1) < 0
     for seed, bid, step in [(0, 0, 0), (1, 123456789, 7), (2**63 + 5, 2**33 + 17, 2**31 + 3)]:
         assert L.qttt_hash(seed, bid, step) == oracle.hash64(seed, bid, step)

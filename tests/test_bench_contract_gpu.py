@@ -1,4 +1,5 @@
-"""bench.py's output contract (one JSON line with the driver's fields + roofline + cpu_baseline)."""
+"""bench.py's output contract (one JSON line with the driver's fields + roofline + cpu_baseline),
+its single clock, and its self-launch of N ranks."""
 import json
 import os
 import subprocess
@@ -10,9 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
+def run_bench(*args, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)                      # a clean environment: no launcher above us
+    e.update(env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=900, env=e)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -20,19 +25,28 @@ def run_bench(*args):
 
 
 def test_bench_json_contract_small_batch():
-    d = run_bench("--boards", "65536", "--steps", "40", "--warmup", "5")
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    d = run_bench("--boards", "65536", "--steps", "40", "--warmup", "5", "--cpu-budget", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline", "clock", "regions", "host_wall_ms_per_step"):
         assert k in d, k
     assert d["metric"] == "env_steps_per_sec" and d["unit"] == "steps/s" and d["higher_is_better"] is True
-    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 == d["ranks_seen"] and d["steps"] == 40 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["config"]["replay_matches_recording"] is True
+    assert d["regions"] >= 5
     r = d["roofline"]
+    sb = d["config"]["state_bytes_per_board"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["algorithmic_bytes_per_launch"] == 47 * 65536
-    assert abs(d["value"] - 65536 * 40 / (d["ms_per_step"] * 1e-3 * 40)) / d["value"] < 1e-6
+    assert r["algorithmic_bytes_per_board_step"] == 2 * sb + 7
+    assert r["algorithmic_bytes_per_launch"] == (2 * sb + 7) * 65536
+    # ONE clock: value, ms_per_step and the roofline fraction are the same measurement
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    assert abs(d["value"] * (2 * sb + 7) / 8e12 - r["frac"]) / r["frac"] < 1e-9
+    assert abs(r["launch_us"] - d["ms_per_step"] * 1e3) < 1e-9
+    assert d["host_wall_ms_per_step"] >= d["ms_per_step"] * 0.98
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "steps/s" and c["cores"] >= 1 and c["value"] > 1e6
     assert c["python_interpreter_steps_per_s"] > 1e4
@@ -41,5 +55,35 @@ def test_bench_json_contract_small_batch():
 def test_bench_modes_agree_on_the_episode_counters():
     a = run_bench("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline")
     b = run_bench("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--mode", "random")
-    assert a["config"]["episodes_finished"] == b["config"]["episodes_finished"] > 0
-    assert b["config"]["replay_matches_recording"] is True
+    c = run_bench("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--mode", "gym")
+    assert a["config"]["episodes_finished"] == b["config"]["episodes_finished"] == c["config"]["episodes_finished"] > 0
+    assert b["config"]["replay_matches_recording"] is True and c["config"]["replay_matches_recording"] is True
+    sb = c["config"]["state_bytes_per_board"]
+    assert c["roofline"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7 + 30
+
+
+def test_bench_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` with a clean environment must itself start 2 ranks (here both on the
+    one GPU of the box, rendezvous over gloo) and report what the process group saw."""
+    d = run_bench("--gpus", "2", "--boards", "32768", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                  env={"QTTT_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["config"]["self_launched"] is True and d["config"]["dist_backend"] == "gloo"
+    assert d["config"]["boards_total"] == 65536
+    assert d["config"]["board_offset_last_rank"] == 32768          # shard 1 starts at global board B
+    assert d["config"]["parallelism"] == "shard2"
+    assert d["config"]["replay_matches_recording"] is True
+    assert abs(d["value"] - 2 * 32768 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
+def test_bench_refuses_more_ranks_than_gpus_on_rccl():
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QTTT_DIST_BACKEND"):
+        e.pop(k, None)
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--boards", "4096",
+                          "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=600, env=e)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

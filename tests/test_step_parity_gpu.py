@@ -200,7 +200,7 @@ def test_empty_batch_and_argument_errors():
     L = _native.lib()
     assert L.qttt_reset(None, 5, None) == -1
     assert L.qttt_reset(None, -1, None) == -2
-    assert L.qttt_state_bytes(1 << 20) == 20 << 20
+    assert L.qttt_state_bytes(1 << 20) == 16 << 20
     env = VecEnv(4)
     with pytest.raises(ValueError):
         env.step_raw(torch.zeros((4, 2), dtype=torch.int64, device="cuda"))

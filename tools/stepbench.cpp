@@ -125,8 +125,7 @@ int main(int argc, char **argv) {
         libs.push_back(L);
     }
     void *state; uint8_t *actions, *term; float *reward;
-    const int64_t sb_per_board = libs[0].state_bytes(64) / 64;   // 16 or 20, by build
-    CK(hipMalloc(&state, std::max<int64_t>(libs[0].state_bytes(n), 20 * ((n + 63) & ~63ll))));
+    CK(hipMalloc(&state, 20 * ((n + 63) & ~63ll)));               // room for either layout (16 or 20 B/board)
     CK(hipMalloc(&actions, (size_t)T * n * 2));
     CK(hipMalloc(&reward, n * 4));
     CK(hipMalloc(&term, n));
@@ -238,8 +237,9 @@ int main(int argc, char **argv) {
                ms * 1e3 / KW, n / (ms * 1e3 / KW) * 1e-3);
     }
     double bytes = 47.0 * n;
-    const double lib_bytes = (2.0 * sb_per_board + 7.0) * n;   // algorithmic bytes of the library's layout
     for (auto &L : libs) {
+        const int64_t sb_per_board = L.state_bytes(64) / 64;      // 16 or 20, by build
+        const double lib_bytes = (2.0 * sb_per_board + 7.0) * n;  // algorithmic bytes of the library's layout
         std::sort(L.us.begin(), L.us.end());
         printf("step  %-44s us/launch min %6.2f med %6.2f  %6.1f Gsteps/s %5.0f GB/s (%d B state)\n", L.spec.c_str(), L.us.front(),
                L.us[L.us.size() / 2], n / L.us.front() * 1e-3, lib_bytes / L.us.front() * 1e-3, (int)sb_per_board);
