@@ -294,8 +294,10 @@ void qo_step_batch(qo_board *b, int64_t n, const uint8_t *actions, const uint8_t
 void qo_ind2move(int n, int *lo, int *hi) {               /* mcts.py:339-343 */
     /* the reference inverts the triangular numbering with a float sqrt; the table it produces
      *  is lexicographic pairs (0,1),(0,2)..(7,8) — restated exactly. */
+    /* n outside 0..35 is not an action (the reference's formula gives (8,9) for 36 and a math
+     * domain error beyond): the loop stops at i = 8, so hi > 8 and make_move rejects it. */
     int i = 0, base = 0;
-    while (n >= base + (8 - i)) { base += 8 - i; ++i; }
+    while (i < 8 && n >= base + (8 - i)) { base += 8 - i; ++i; }
     *lo = i;
     *hi = i + 1 + (n - base);
 }
@@ -314,6 +316,7 @@ void qo_update_winner(const qo_board *b, int *winner, int *terminal) {   /* mcts
 int qo_expand(const qo_board *parent, int action36, qo_board child[2], int winner[2],
               int terminal[2], uint64_t legal_mask[2]) {  /* mcts.py:233-267 */
     int lo, hi, consumed;
+    if (action36 < 0 || action36 > 35) return 0;          /* not an action: no children */
     qo_ind2move(action36, &lo, &hi);
     child[0] = *parent;                                   /* mcts.py:235-241 copies */
     if (qo_make_move(&child[0], lo, hi, 0, &consumed) != QO_OK) return 0;

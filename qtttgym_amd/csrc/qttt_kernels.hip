@@ -118,6 +118,12 @@ __device__ __forceinline__ void store_stream(V *p, const V &v) {
 }
 
 __device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
+// v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xFFFFFFFF for 0
+__device__ __forceinline__ u32 ffbl_raw(u32 x) {
+    u32 r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 
 #ifdef QTTT_DEBUG_STAMPS
 __device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench stamps)
@@ -261,7 +267,7 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
         u64 comps = (u64)Q1 | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
         const u32 mlo = (u32)(comps >> lo) & SLOT_LSB;   // slot holding lo (board.py:28-33)
         const u32 mhi = (u32)(comps >> hi) & SLOT_LSB;   // slot holding hi (board.py:35-40)
-        const bool has_lo = mlo != 0u, has_hi = mhi != 0u;
+        const bool has_lo = mlo != 0u;
         const bool cyc = (mlo & mhi) != 0u;              // board.py:42: same component -> cycle
         // x: the square that becomes the child end of the new edge; on a cycle it is the square
         // the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi), which becomes the root
@@ -288,29 +294,33 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
         P0 = (u32)P;
         P1 = (u32)(P >> 32);
         // board.py:19: append.  Only x = lo^hi is kept (see the header): round n <= 7 goes to its
-        // nibble of Q0 (rotate by 4n+4), every move to the `last x` field.
-        const u32 xx4 = (a ^ b) << 2;
-        Q0 ^= rotr32(xx4, n4 + 4u);
-        P1 = (P1 & ~(0xFu << P1_LX_SHIFT)) | (xx4 << (P1_LX_SHIFT - 2u));
-        P1 += 1u << P1_N_SHIFT;
-        // ---- board.py:42-69 on the cached qstructs, all three cases in one straight line ----
-        const u32 shi = (u32)__builtin_ctz(mhi | 0x80000000u);          // 31 when hi is in no slot
-        const u32 c1 = has_hi ? (u32)(comps >> shi) & 0x1FFu : 0u;      // component of hi
-        const bool uni = has_lo && has_hi && !cyc;                      // board.py:58-61
-        // first empty slot (slots are compact): 9 * number of non-empty slots among 0..2
+        // nibble of Q0 (x*4 rotated right by 4n+4, i.e. x<<16 rotated by 4n+18), every move to the
+        // `last x` field; n += 1.
+        const u32 x16 = (a ^ b) << 16;
+        Q0 ^= rotr32(x16, n4 + 18u);
+        P1 = ((P1 & ~(0xFu << P1_LX_SHIFT)) | x16) + (1u << P1_N_SHIFT);
+        // ---- board.py:42-69 on the cached qstructs, all cases in one straight line ----
+        // ffbl_raw(0) = -1, a 64-bit shift by -1 (= 63) gives 0: c1 = component of hi, 0 if none
+        const u32 c1 = (u32)(comps >> (ffbl_raw(mhi) & 63u)) & 0x1FFu;
+        // the slot the move goes to (board.py:58-69): lo's, else hi's, else the first empty one.
+        // Slots are compact, so the first empty slot's bit lies above every occupied slot's and a
+        // single "lowest set bit" picks the right one: nz = non-empty flags of slots 0..2 (bits
+        // 8,17,26), t = the LSBs of slots 0..count, t & ~(t >> 9) = the LSB of slot `count`.
+        const u32 tsel = has_lo ? mlo : mhi;
         const u32 c32 = (u32)comps;
         const u32 nz = (((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u;
-        const u32 s_new = (u32)__builtin_popcount(nz) * 9u;
-        const u32 slo = (u32)__builtin_ctz(mlo | 0x80000000u);
-        const u32 sT = has_lo ? slo : (has_hi ? shi : s_new);           // board.py:62-69
-        comps |= (u64)(pm | (uni ? c1 : 0u)) << sT;
-        // pop hi's slot on a cycle (board.py:56) or a union (board.py:61)
-        const u32 low = ((cyc || uni) ? mhi : 0u) - 1u;                 // all ones = keep everything
-        const u32 lowh = (u32)((int)low >> 31);
-        const u64 sh9 = comps >> 9;
-        Q1 = ((u32)comps & low) | ((u32)sh9 & ~low);
-        const u32 chi = ((u32)(comps >> 32) & lowh) | ((u32)(sh9 >> 32) & ~lowh);
-        P1 = (P1 & ~(0xFu << P1_CHI_SHIFT)) | (chi << P1_CHI_SHIFT);
+        const u32 t = (nz << 1) | 1u;
+        const u32 sT = ffbl_raw(tsel | (t & ~(t >> 9)));
+        // the move's squares join the slot; so does hi's component (a no-op unless this is a
+        // union, board.py:58-61: on a cycle or when only hi is in a slot it is that slot already)
+        comps |= (u64)(pm | c1) << sT;
+        // pop hi's slot on a cycle (board.py:56) or a union (board.py:61) <=> both are in a slot
+        const u32 mpop = has_lo ? mhi : 0u;
+        const u32 low = mpop - 1u;                                      // all ones = keep everything
+        const u32 chi2 = (u32)(comps >> 32);
+        Q1 = ((u32)comps & low) | (__builtin_amdgcn_alignbit(chi2, (u32)comps, 9u) & ~low);
+        // after a pop at most three slots are left: bits 27..35 are empty
+        P1 = (P1 & ~(0xFu << P1_CHI_SHIFT)) | ((mpop ? 0u : chi2) << P1_CHI_SHIFT);
         // board.py:44-56 + qeval.py:5-51: on a cycle every square of the component goes classical
         // and already holds its parent edge's round; x holds the closing move's round
         P1 |= (cyc ? c1 : 0u) << P1_CL_SHIFT;
@@ -319,16 +329,18 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
     // round on each classical square -> X / O masks -> table lookup.  Codes are complemented, so
     // a set low bit means an EVEN round (X).  All masks here are "times four" (bit v+2 = square v).
     // Eight classical squares = the autofill of board.py:22-25 is due: the ninth square counts as
-    // X (round 8) and the game is over.
+    // X (round 8) — with 8 or 9 classical squares X is simply "everything that is not O".
     const u32 par4 = P0 & 0x44444444u;
     const u32 even4 = __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
-                      (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 & 4u) << 8);
+                      (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 << 8) & 0x400u);
     const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;                // bits 20,21 of P1 are 0
     const u32 pc = (u32)__builtin_popcount(cl4);
-    const u32 fill4 = pc == 8u ? (cl4 ^ 0x7FCu) : 0u;
-    const u32 win = (u32)lut[(cl4 & even4) | fill4] | (u32)lut[cl4 & ~even4];
-    // env.py:51: a line, or len(moves) > 8  <=>  at least 8 classical squares
-    P1 = (P1 & ~P1_DONE) | ((win != 0u || pc >= 8u) ? P1_DONE : 0u);
+    const u32 O4 = cl4 & ~even4;
+    const u32 X4 = pc >= 8u ? (O4 ^ 0x7FCu) : (cl4 & even4);
+    const u32 win = (u32)lut[X4] | (u32)lut[O4];
+    // env.py:51: a line, or len(moves) > 8  <=>  at least 8 classical squares.  win is 0 or 0x7F,
+    // pc <= 9: bit 3 of (win | pc & 8) is the answer
+    P1 = (P1 & ~P1_DONE) | (((win | (pc & 8u)) << 28) & P1_DONE);
     return win;
 }
 
@@ -411,15 +423,64 @@ __device__ inline void obs_copy_out(uint8_t *lds, const ObsOut &o, int64_t first
     tile_copy_out<BLOCK>(o.turn + first, lds, valid);
 }
 
+// Compaction table of the observation's move lists.  A list has four candidate entries in fixed
+// places (byte j of a register = the move of one round, byte 3 the EARLIEST round); a 4-bit
+// liveness mask m selects the v_perm_b32 selectors that gather the live ones in move order into
+// two dwords of (lo, hi) byte pairs — sources: lo bytes = selector 0..3, hi bytes = 4..7 — and pad
+// the rest with 0xFF (selector 0x0D).
+struct ObsLut {
+    u32 sel[16][2];
+    constexpr ObsLut() : sel() {
+        for (u32 m = 0; m < 16; ++m) {
+            u32 pos[4] = {0x0D0Du, 0x0D0Du, 0x0D0Du, 0x0D0Du};
+            u32 p = 0;
+            for (int j = 3; j >= 0; --j)
+                if (m >> j & 1u) pos[p++] = (u32)j | ((4u + (u32)j) << 8);
+            sel[m][0] = pos[0] | (pos[1] << 16);
+            sel[m][1] = pos[2] | (pos[3] << 16);
+        }
+    }
+};
+__constant__ ObsLut g_obs_lut = ObsLut();
+constexpr u32 OBS_LUT_BYTES = 128;
+
+template <int BLOCK>
+__device__ inline void fill_obs_lut(u32 *dst) {
+    const u32 *src = &g_obs_lut.sel[0][0];
+    for (u32 w = threadIdx.x; w < 32u; w += BLOCK) dst[w] = src[w];
+}
+
+// One move list of the observation.  h: byte j = holder square + 1 of the candidate move j (0 =
+// not live), x: byte j = lo^hi of that move.  Returns the (lo,hi) pairs of the live moves in move
+// order as w0 | w1 (two pairs each, 0xFF-padded) and their number.
+__device__ __forceinline__ u32 obs_list(u32 h, u32 x, const u32 *olut, u32 &w0, u32 &w1) {
+    const u32 live01 = ((h + 0x0F0F0F0Fu) >> 4) & 0x01010101u;        // 1 where h != 0 (h <= 9)
+    const u32 idx = __builtin_amdgcn_udot4(live01, 0x08040201u, 0u, false);
+    const u32 c = h - live01;                                          // the holder square
+    const u32 o = c ^ x;                                               // the other end of its move
+    // bytewise min / max of c, o (both < 16): bit 4 of (c | 0x10) - o survives iff c >= o
+    const u32 ge = (((c | 0x10101010u) - o) >> 4) & 0x01010101u;
+    const u32 gm = (ge << 8) - ge;
+    const u32 lo = (o & gm) | (c & ~gm);
+    const u32 hi = c ^ o ^ lo;
+    const u32 s0 = olut[idx * 2u], s1 = olut[idx * 2u + 1u];
+    w0 = __builtin_amdgcn_perm(hi, lo, s0);
+    w1 = __builtin_amdgcn_perm(hi, lo, s1);
+    return (u32)__builtin_popcount(idx);
+}
+
 // The observation of one board, from its packed words, into row b of the tiles.
-//   classical (env.py:71,82): Board.board, -1 for an empty square;
+//   classical (env.py:71,82): Board.board, -1 for an empty square: nibbles -> bytes (two v_perm),
+//     15 - code where classical, 0xFF elsewhere;
 //   q_states_p1 / p2 (env.py:72-77): (lo,hi) of the un-collapsed moves of even / odd round in move
 //     order, 255-padded.  An un-collapsed move is the parent edge of exactly one non-classical
-//     square c (its holder), and is (c, c ^ x).  Lc collects the codes of the live edges; the place
-//     of an edge in its list is the number of live edges of the same parity with a smaller round
-//     (= a larger code), so every holder writes its pair straight to its final place;
+//     square c (its holder) and is (c, c ^ x).  H inverts the holders: nibble code-8 = holder + 1
+//     (one 64-bit shift per square: a square that holds no live edge has code 0 and lands in the
+//     low word, which is ignored).  Nibble j of H and nibble j of the x word Q0 >>> 2 belong to
+//     the same round 7-j, odd nibbles = even rounds = player 1, so both lists are built bytewise
+//     for four moves at a time and compacted with one table lookup (obs_list);
 //   turn (env.py:83): len(moves) % 2, the implicit autofill move included.
-__device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles &T, u32 b) {
+__device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles &T, u32 b, const u32 *olut) {
     u64 P = (u64)P0 | ((u64)P1 << 32);
     u32 cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
     const u32 n = (P1 >> P1_N_SHIFT) & 0xFu;
@@ -430,7 +491,6 @@ __device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles
         P |= (u64)(15u - n) << (4u * idx + 2u);
         cl = 0x1FFu;
     }
-    // ---- classical: nibbles -> bytes, 15 - code where classical, 0xFF (-1) elsewhere
     const u32 W = (u32)(P >> 2);
     const u32 ev = W & 0x0F0F0F0Fu, od = (W >> 4) & 0x0F0F0F0Fu;
     const u32 c03 = __builtin_amdgcn_perm(od, ev, 0x05010400u);          // codes of squares 0..3
@@ -438,8 +498,9 @@ __device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles
     const u32 c8 = (u32)(P >> 34) & 0xFu;
     const u32 t03 = __umul24(cl & 0xFu, 0x204081u) & 0x01010101u;        // bit v -> byte v
     const u32 t47 = __umul24((cl >> 4) & 0xFu, 0x204081u) & 0x01010101u;
-    const u32 o03 = (c03 ^ 0x0F0F0F0Fu) | ~((t03 << 8) - t03);
-    const u32 o47 = (c47 ^ 0x0F0F0F0Fu) | ~((t47 << 8) - t47);
+    const u32 m03 = (t03 << 8) - t03, m47 = (t47 << 8) - t47;            // 0xFF where classical
+    const u32 o03 = (c03 ^ 0x0F0F0F0Fu) | ~m03;
+    const u32 o47 = (c47 ^ 0x0F0F0F0Fu) | ~m47;
     const u32 o8 = (cl & 0x100u) ? (c8 ^ 0xFu) : 0xFFu;
     uint8_t *rc = T.cl + b * 9u;
     rc[0] = (uint8_t)o03;
@@ -451,32 +512,33 @@ __device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles
     rc[6] = (uint8_t)(o47 >> 16);
     rc[7] = (uint8_t)(o47 >> 24);
     rc[8] = (uint8_t)o8;
-    // ---- live edges by code: a non-classical square with a parent edge holds code 8..15 (round 7..0)
-    u32 Lc = 0;
-#pragma unroll
-    for (u32 v = 0; v < 9; ++v) {
-        const u32 c = (u32)(P >> (4u * v + 2u)) & 0xFu;
-        Lc |= ((cl >> v) & 1u) ? 0u : (1u << c);
-    }
-    Lc &= 0xFF00u;                                        // code 0 = root / isolated
-    uint8_t *r1 = T.p1 + b * 10u, *r2 = T.p2 + b * 8u;
-#pragma unroll
-    for (u32 k = 0; k < 5; ++k) *reinterpret_cast<uint16_t *>(r1 + 2u * k) = (uint16_t)0xFFFFu;
-    *reinterpret_cast<u64 *>(r2) = ~0ull;
-#pragma unroll
-    for (u32 v = 0; v < 9; ++v) {
-        const u32 c = (u32)(P >> (4u * v + 2u)) & 0xFu;
-        if (!((cl >> v) & 1u) && c != 0u) {
-            const u32 o = v ^ ((rotr32(Q0, c * 4u) >> 2) & 0xFu);       // the other end of the edge
-            const u32 pair = min(v, o) | (max(v, o) << 8);
-            const u32 odd = c & 1u;                                      // odd code = even round = player 1
-            const u32 rank = (u32)__builtin_popcount(Lc & (0x5500u << odd) & (0xFFFFFFFEu << c));
-            uint8_t *dst = (odd ? r1 : r2) + 2u * rank;
-            *reinterpret_cast<uint16_t *>(dst) = (uint16_t)pair;
-        }
-    }
-    T.l1[b] = (uint8_t)__builtin_popcount(Lc & 0xAA00u);
-    T.l2[b] = (uint8_t)__builtin_popcount(Lc & 0x5500u);
+    // ---- holders by code: four times the code of a square that holds a live edge (0 otherwise)
+    const u32 S03 = (c03 & ~m03) << 2, S47 = (c47 & ~m47) << 2, S8 = (cl & 0x100u) ? 0u : c8 << 2;
+    u32 H = 0;
+#define QTTT_HOLD(v, S, k) H |= (u32)(((u64)((v) + 1u) << (((S) >> (8 * (k))) & 0xFFu)) >> 32)
+    QTTT_HOLD(0, S03, 0);
+    QTTT_HOLD(1, S03, 1);
+    QTTT_HOLD(2, S03, 2);
+    QTTT_HOLD(3, S03, 3);
+    QTTT_HOLD(4, S47, 0);
+    QTTT_HOLD(5, S47, 1);
+    QTTT_HOLD(6, S47, 2);
+    QTTT_HOLD(7, S47, 3);
+    QTTT_HOLD(8, S8, 0);
+#undef QTTT_HOLD
+    const u32 X = rotr32(Q0, 2);
+    u32 a0, a1, b0, b1;
+    const u32 n1 = obs_list((H >> 4) & 0x0F0F0F0Fu, (X >> 4) & 0x0F0F0F0Fu, olut, a0, a1);   // even rounds
+    const u32 n2 = obs_list(H & 0x0F0F0F0Fu, X & 0x0F0F0F0Fu, olut, b0, b1);                 // odd rounds
+    uint16_t *r1 = reinterpret_cast<uint16_t *>(T.p1 + b * 10u);
+    r1[0] = (uint16_t)a0;
+    r1[1] = (uint16_t)(a0 >> 16);
+    r1[2] = (uint16_t)a1;
+    r1[3] = (uint16_t)(a1 >> 16);
+    r1[4] = (uint16_t)0xFFFFu;                            // round 8 can never be un-collapsed
+    *reinterpret_cast<u64 *>(T.p2 + b * 8u) = (u64)b0 | ((u64)b1 << 32);
+    T.l1[b] = (uint8_t)n1;
+    T.l2[b] = (uint8_t)n2;
     T.tn[b] = (uint8_t)((n + (fill ? 1u : 0u)) & 1u);                   // env.py:83
 }
 
@@ -498,6 +560,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
     __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
+    __shared__ __attribute__((aligned(16))) u32 olut[OBS ? OBS_LUT_BYTES / 4 : 4];
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -519,6 +582,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
     fill_line_lut_nosync<QTTT_BLOCK>(lut);
     if (SAMPLE) fill_policy_lut<QTTT_BLOCK>(plut);
+    if (OBS) fill_obs_lut<QTTT_BLOCK>(olut);
     ObsTiles T;
     if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
     __syncthreads();
@@ -553,7 +617,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
             q.v[k] = (u64)Q0 | ((u64)Q1 << 32);
             rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f
             tm.v[k] = (uint8_t)(P1 >> 31);
-            if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k);
+            if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k, olut);
         }
         store_stream(&reinterpret_cast<V64 *>(pP + ib)[g], p);
         store_stream(&reinterpret_cast<V64 *>(pQ + ib)[g], q);
@@ -772,13 +836,16 @@ __device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) 
 // and the same obs_board() as the fused step kernel.
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(QTTT_COLD_BLOCK)];
+    __shared__ __attribute__((aligned(16))) u32 olut[OBS_LUT_BYTES / 4];
+    fill_obs_lut<QTTT_COLD_BLOCK>(olut);
+    __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * QTTT_COLD_BLOCK;
     const int64_t i = base + threadIdx.x;
     const u32 valid = (u32)min((int64_t)QTTT_COLD_BLOCK, n - base);
     const ObsTiles T = obs_tiles<QTTT_COLD_BLOCK>(otile, obs, base);
     if (threadIdx.x < valid) {
         const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
-        obs_board((u32)P, (u32)(P >> 32), (u32)Q, T, threadIdx.x);
+        obs_board((u32)P, (u32)(P >> 32), (u32)Q, T, threadIdx.x, olut);
     }
     __syncthreads();
     obs_copy_out<QTTT_COLD_BLOCK, QTTT_COLD_BLOCK>(otile, obs, base, valid);
