@@ -109,6 +109,25 @@ int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *boa
 int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
                 const uint16_t *qmask, const uint8_t *n_q, int64_t n, void *stream);
 
+/* Board.make_move (board.py:9-25), Board.update_qstructs (board.py:27-69) and Board.check_win
+ * (board.py:71-115) for callers that hold the reference's Python attributes (the `Board` duck type L3
+ * code subclasses, mcts.py:9-17): n records of QTTT_BOARD_RECORD_BYTES in, n out, ONE launch
+ * (import, the same step function as qttt_step, export, check_win).  The records only need to be
+ * device-accessible: pinned host memory works, and is what the single-board façade uses.
+ *   byte  0..17  moves u8[9][2] (255 pad)     18 n_moves     19..27 board i8[9]     28 n_q
+ *         29     op (QTTT_OP_*)               30..37 qmask u16[4] little endian
+ *         38,39  the move's two squares       40 collapse bit (stand-in for qeval.py:35)
+ *   out only:    41 1 = make_move would raise (state unchanged)   44..47 reward f32 (env.py:49)
+ *         48     terminated (env.py:51)       49,50 check_win p1_round, p2_round (i8)
+ * QTTT_OP_MAKE_MOVE: validate, append, entangle / collapse, autofill.  QTTT_OP_UPDATE_QSTRUCTS: the
+ * same without the autofill — moves must NOT yet contain the move (the caller appended it: drop it
+ * from the record).  QTTT_OP_CHECK_WIN: no move, outputs only. */
+#define QTTT_BOARD_RECORD_BYTES 64
+#define QTTT_OP_MAKE_MOVE 0
+#define QTTT_OP_UPDATE_QSTRUCTS 1
+#define QTTT_OP_CHECK_WIN 2
+int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *stream);
+
 /* Synthetic policy for measurement: uniform over legal unordered pairs
  * (GameState.actions rule, mcts.py:20-27) in ind2move order (mcts.py:339-343), index and
  * collapse bit from the counter hash of (seed, board_offset+i, step_idx).  actions u8[n,2]. */

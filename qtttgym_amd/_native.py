@@ -10,6 +10,8 @@ LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.s
 ABI_VERSION = 2
 FLAG_AUTO_RESET = 1
 FLAG_FUSED = 2
+BOARD_RECORD_BYTES = 64
+OP_MAKE_MOVE, OP_UPDATE_QSTRUCTS, OP_CHECK_WIN = 0, 1, 2
 
 # every symbol include/qttt.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
@@ -27,6 +29,7 @@ SIGNATURES = {
     "qttt_check_win": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_export": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_import": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_board_op": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
     "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_expand": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

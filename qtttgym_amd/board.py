@@ -3,9 +3,11 @@ qeval.py, display.py) backed by the HIP library.
 
 `Board` keeps the reference's *attributes* (`.moves`, `.board`, `.qstructs`, `.qeval`) as plain
 Python objects because L3 callers subclass it and assign them directly (mcts.py:11-17,241).
-`make_move` / `check_win` ship those attributes to the device (qttt_import), run the same fused
-kernel `VecEnv` uses on a 1-board batch (qttt_step / qttt_check_win) and read the result back
-(qttt_export).  It is a compatibility surface, not a fast path: batch work belongs in `VecEnv`.
+`make_move` / `update_qstructs` / `check_win` write those attributes into one 64-byte record in
+pinned host memory, run qttt_board_op (import -> the same step function the batch kernels use ->
+export + check_win, ONE kernel launch reading and writing the pinned records directly) and take the
+attributes back from the out record.  It is a compatibility surface, not a fast path (a launch and
+a synchronise per call): batch work belongs in `VecEnv`.
 """
 import random
 
@@ -44,16 +46,62 @@ class QEvalClassic:
         return out
 
 
-_scratch = None
+class _Staging:
+    """One 64-byte record in and one out (include/qttt.h: qttt_board_op), both in pinned host memory
+    that the kernel reads and writes directly: a Board call is one kernel launch and one stream
+    synchronise — no host-to-device or device-to-host copy calls at all."""
+
+    def __init__(self):
+        if not torch.cuda.is_available():
+            raise _native.QtttNativeError("no HIP device visible (torch.cuda.is_available() is False); "
+                                          "Board runs its rules in libqttt_hip.so, there is no CPU path")
+        self.lib = _native.lib()
+        nb = _native.BOARD_RECORD_BYTES
+        self.t_in = torch.zeros(nb, dtype=torch.uint8).pin_memory()
+        self.t_out = torch.zeros(nb, dtype=torch.uint8).pin_memory()
+        self.a_in = self.t_in.numpy()          # plain memory views of the pinned buffers
+        self.a_out = self.t_out.numpy()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def run(self, board, op, lo=0, hi=0, bit=0, drop_last_move=False):
+        """Ships board's attributes + the move, runs qttt_board_op, returns the out record."""
+        a = self.a_in
+        moves = board.moves[:-1] if drop_last_move else board.moves
+        n = min(len(moves), 9)
+        a[0:18] = 255
+        for i in range(n):
+            m = moves[i]
+            a[2 * i], a[2 * i + 1] = m[0] & 255, m[1] & 255
+        a[18] = n
+        for v in range(9):
+            a[19 + v] = board.board[v] & 255
+        nq = min(len(board.qstructs), 4)
+        a[28] = nq
+        a[29] = op
+        for k in range(4):
+            mask = 0
+            if k < nq:
+                for x in board.qstructs[k]:
+                    mask |= 1 << int(x)
+            a[30 + 2 * k], a[31 + 2 * k] = mask & 255, mask >> 8
+        a[38], a[39], a[40] = lo, hi, bit
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            _native.check(self.lib.qttt_board_op(self.t_in.data_ptr(), self.t_out.data_ptr(), 1,
+                                                 stream.cuda_stream), "qttt_board_op")
+            stream.synchronize()
+        return self.a_out
 
 
-def _scratch_env():
-    """One 1-board device batch shared by every Board façade in the process."""
-    global _scratch
-    if _scratch is None:
-        from .vec_env import VecEnv
-        _scratch = VecEnv(1, device="cuda")
-    return _scratch
+_staging = None
+
+
+def _stage():
+    """The staging records shared by every Board façade in the process."""
+    global _staging
+    if _staging is None:
+        _staging = _Staging()
+    return _staging
 
 
 class Board:
@@ -64,37 +112,25 @@ class Board:
         self.qeval = qevaluator                           # board.py:7
 
     # ------------------------------------------------------------------ device round trip
-    def _upload(self, env):
-        moves = torch.full((1, 9, 2), 255, dtype=torch.uint8)
-        for i, m in enumerate(self.moves[:9]):
-            moves[0, i, 0], moves[0, i, 1] = int(m[0]), int(m[1])
-        qmask = torch.zeros((1, 4), dtype=torch.int16)
-        for i, s in enumerate(self.qstructs[:4]):
-            qmask[0, i] = sum(1 << int(x) for x in s)
-        env.import_boards(moves, torch.tensor([len(self.moves)], dtype=torch.uint8),
-                          torch.tensor([self.board], dtype=torch.int8), qmask,
-                          torch.tensor([len(self.qstructs)], dtype=torch.uint8))
+    def _adopt(self, o):
+        """Takes the attributes back from an out record."""
+        n = int(o[18])
+        self.moves = [(int(o[2 * i]), int(o[2 * i + 1]), i) for i in range(n)]
+        self.board[:] = [int(x) - 256 if x > 127 else int(x) for x in o[19:28]]   # in place: env.py:71,82 aliasing
+        self.qstructs = [set(s for s in range(9) if (int(o[30 + 2 * k]) | int(o[31 + 2 * k]) << 8) >> s & 1)
+                         for k in range(int(o[28]))]
+        # the out record carries check_win of the new state (a function of .board alone,
+        # board.py:71-115): remembered, keyed by the board it belongs to
+        self._win = (tuple(self.board), self._i8(o[49]), self._i8(o[50]))
 
-    def _download(self, env):
-        ex = {k: v.cpu() for k, v in env.export_boards().items()}
-        n = int(ex["n_moves"][0])
-        self.moves = [(int(ex["moves"][0, i, 0]), int(ex["moves"][0, i, 1]), i) for i in range(n)]
-        self.board[:] = [int(x) for x in ex["board"][0]]   # in place: env.py:71,82 aliasing
-        self.qstructs = [set(s for s in range(9) if int(ex["qmask"][0, i]) >> s & 1)
-                         for i in range(int(ex["n_q"][0]))]
+    @staticmethod
+    def _i8(x):
+        x = int(x)
+        return x - 256 if x > 127 else x
 
-    def _make_move_device(self, lo, hi, bit, autofill=True):
-        env = _scratch_env()
-        self._upload(env)
-        act = torch.tensor([[lo, hi]], dtype=torch.uint8, device=env.device)
-        bits = torch.tensor([bit], dtype=torch.uint8, device=env.device)
-        env.step_raw(act, bits)
-        self._download(env)
-        if not autofill and len(self.moves) and self.moves[-1][0] == self.moves[-1][1]:
-            # QEvalClassic.eval() on its own never autofills (that is board.py:22-25's job)
-            sq = self.moves[-1][0]
-            self.moves.pop()
-            self.board[sq] = -1
+    def _make_move_device(self, lo, hi, bit, autofill=True, drop_last_move=False):
+        op = _native.OP_MAKE_MOVE if autofill else _native.OP_UPDATE_QSTRUCTS
+        self._adopt(_stage().run(self, op, lo, hi, bit, drop_last_move))
 
     @classmethod
     def from_export(cls, ex, index=0, qevaluator=None):
@@ -136,7 +172,7 @@ class Board:
             bit = 1 if self.qeval.choose(lo, hi) == hi else 0
         self._make_move_device(lo, hi, bit)
 
-    def _make_move_custom_eval(self, lo, hi, m0):
+    def _make_move_custom_eval(self, lo, hi, m0, autofill=True):
         """Plug point board.py:2,7,51: a caller-supplied evaluator decides the collapse.  Its
         answer is applied verbatim (board.py:53-56), then the autofill (board.py:22-25)."""
         self.moves.append((lo, hi, len(self.moves)))
@@ -146,21 +182,47 @@ class Board:
         for (r, _), o in zip(zipped, outcomes):
             self.board[o] = r
         self.qstructs.pop(m0)
-        if self.board.count(-1) == 1:
+        if autofill and self.board.count(-1) == 1:
             idx = self.board.index(-1)
             self.board[idx] = len(self.moves)
             self.moves.append((idx, idx, len(self.moves)))
 
     def update_qstructs(self, move):
-        raise NotImplementedError(
-            "update_qstructs (board.py:27-69) is fused into the qttt_step kernel; call make_move")
+        """board.py:27-69 on its own: entangle `move` with the components, or — if it closes a cycle —
+        collapse the component (self.board gets the rounds, the component leaves self.qstructs).
+        The reference calls it from make_move right after `self.moves.append(...)` (board.py:19-20)
+        and its collapse branch reads the move back from self.moves, so the contract is the same
+        here: `move` must be the last entry of self.moves.  No validation, no autofill (those are
+        make_move's, board.py:10-15,22-25).  Same device path as make_move."""
+        lo, hi = (move[0], move[1]) if move[0] < move[1] else (move[1], move[0])
+        if not self.moves or (self.moves[-1][0], self.moves[-1][1]) != (lo, hi):
+            raise ValueError("update_qstructs(move): move must be the last entry of self.moves "
+                             "(board.py:19-20 appends it before the call)")
+        m0, m1 = -1, -2
+        for i, s in enumerate(self.qstructs):
+            if lo in s:
+                m0 = i
+                break
+        for j, s in enumerate(self.qstructs):
+            if hi in s:
+                m1 = j
+                break
+        if m0 == m1 and not isinstance(self.qeval, QEvalClassic):
+            self.moves.pop()                                       # _make_move_custom_eval appends it again
+            return self._make_move_custom_eval(lo, hi, m0, autofill=False)
+        bit = 0
+        if m0 == m1:
+            bit = 1 if self.qeval.choose(lo, hi) == hi else 0
+        self._make_move_device(lo, hi, bit, autofill=False, drop_last_move=True)
 
     def check_win(self):
         """board.py:71-115 -> (p1_round, p2_round), -1 = no line."""
-        env = _scratch_env()
-        self._upload(env)
-        p1, p2 = env.check_win()
-        return int(p1[0]), int(p2[0])
+        key = tuple(self.board)
+        w = getattr(self, "_win", None)
+        if w is None or w[0] != key:                                   # .board was assigned by the caller
+            o = _stage().run(self, _native.OP_CHECK_WIN)
+            w = self._win = (key, self._i8(o[49]), self._i8(o[50]))
+        return w[1], w[2]
 
 
 def displayBoard(board):

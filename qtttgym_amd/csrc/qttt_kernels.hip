@@ -746,7 +746,7 @@ __device__ __forceinline__ u32 cold_move_x(u32 Q0, u32 P1, u32 n_real, u32 e) {
     return x;
 }
 
-__device__ __forceinline__ void cold_unpack(u64 P, u64 Q, Cold &s) {
+__device__ __forceinline__ void cold_unpack(u64 P, u64 Q, Cold &s, bool autofill = true) {
     const u32 P1 = (u32)(P >> 32), Q0 = (u32)Q;
     s.n = (P1 >> P1_N_SHIFT) & 0xFu;
     s.cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
@@ -765,7 +765,7 @@ __device__ __forceinline__ void cold_unpack(u64 P, u64 Q, Cold &s) {
         s.set_mv(e, min(c, o) | (max(c, o) << 4));
     }
     // materialise the implicit autofill (board.py:22-25): exactly 8 classical squares
-    if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {
+    if (autofill && __builtin_popcount(s.cl) == 8 && s.n < 9u) {
         const u32 idx = (u32)__builtin_ctz(~s.cl);
         s.set_sq(idx, s.n);                                      // board[idx] = len(self.moves)
         s.cl |= 1u << idx;
@@ -832,23 +832,33 @@ __device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) 
 
 #define QTTT_COLD_BLOCK 256
 
-// Env._observation (env.py:68-85) of stored boards: one board per lane through the same LDS tiles
-// and the same obs_board() as the fused step kernel.
-__global__ __launch_bounds__(QTTT_COLD_BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(QTTT_COLD_BLOCK)];
+// Env._observation (env.py:68-85) of stored boards: two boards per lane (one 16-byte load per
+// plane, as the step kernel) through the same LDS tiles and the same obs_board() as the fused step
+// kernel.  A workgroup owns 2 * QTTT_BLOCK consecutive boards; the last board of an odd batch is
+// read with scalar loads.
+__global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
+    constexpr u32 TILE_BOARDS = QTTT_BLOCK * 2;
+    __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(TILE_BOARDS)];
     __shared__ __attribute__((aligned(16))) u32 olut[OBS_LUT_BYTES / 4];
-    fill_obs_lut<QTTT_COLD_BLOCK>(olut);
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * QTTT_COLD_BLOCK;
-    const int64_t i = base + threadIdx.x;
-    const u32 valid = (u32)min((int64_t)QTTT_COLD_BLOCK, n - base);
-    const ObsTiles T = obs_tiles<QTTT_COLD_BLOCK>(otile, obs, base);
-    if (threadIdx.x < valid) {
-        const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
-        obs_board((u32)P, (u32)(P >> 32), (u32)Q, T, threadIdx.x, olut);
+    fill_obs_lut<QTTT_BLOCK>(olut);
+    const int64_t base = (int64_t)blockIdx.x * TILE_BOARDS;
+    const u32 valid = (u32)min((int64_t)TILE_BOARDS, n - base);
+    const ObsTiles T = obs_tiles<TILE_BOARDS>(otile, obs, base);
+    const u32 b0 = threadIdx.x * 2u;
+    typedef Vec<u64, 2> V64;
+    V64 p, q;
+    if (b0 + 1u < valid) {
+        p = load_stream(&reinterpret_cast<const V64 *>(pP + base)[threadIdx.x]);
+        q = load_stream(&reinterpret_cast<const V64 *>(pQ + base)[threadIdx.x]);
+    } else if (b0 < valid) {
+        p.v[0] = pP[base + b0];
+        q.v[0] = pQ[base + b0];
     }
     __syncthreads();
-    obs_copy_out<QTTT_COLD_BLOCK, QTTT_COLD_BLOCK>(otile, obs, base, valid);
+    if (b0 < valid) obs_board((u32)p.v[0], (u32)(p.v[0] >> 32), (u32)q.v[0], T, b0, olut);
+    if (b0 + 1u < valid) obs_board((u32)p.v[1], (u32)(p.v[1] >> 32), (u32)q.v[1], T, b0 + 1u, olut);
+    __syncthreads();
+    obs_copy_out<QTTT_BLOCK, TILE_BOARDS>(otile, obs, base, valid);
 }
 
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
@@ -887,31 +897,27 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
     n_q[i] = (uint8_t)nq;
 }
 
-// Builds the packed state (incl. the rooted forest) from Board attributes assigned by a caller
+// Builds the unpacked board (incl. the rooted forest) from Board attributes assigned by a caller
 // (mcts.py:11-17,241 assign .board/.moves/.qstructs directly).  Not a hot path.
-__global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
-    u64 *pP, u64 *pQ, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
-    const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Cold s;
-    s.n = min((u32)n_moves[i], 9u);
+__device__ __forceinline__ void cold_from_attrs(const uint8_t *moves, u32 n_moves, const int8_t *board,
+                                                const uint16_t *qmask, u32 n_q, Cold &s) {
+    s.n = min(n_moves, 9u);
     s.cl = 0;
     s.mvq = 0;
     s.mv8 = 0;
     for (u32 t = 0; t < s.n; ++t)
-        s.set_mv(t, (u32)(moves[i * 18 + t * 2] & 0xFu) | ((u32)(moves[i * 18 + t * 2 + 1] & 0xFu) << 4));
+        s.set_mv(t, (u32)(moves[t * 2] & 0xFu) | ((u32)(moves[t * 2 + 1] & 0xFu) << 4));
     s.sq = 0xFFFFFFFFFull;
     for (u32 v = 0; v < 9; ++v) {
-        const int bv = board[i * 9 + v];
+        const int bv = board[v];
         if (bv >= 0) {
             s.cl |= 1u << v;
             s.set_sq(v, (u32)bv & 0xFu);
         }
     }
-    const u32 nq = min((u32)n_q[i], 4u);
+    const u32 nq = min(n_q, 4u);
     s.comps = 0;
-    for (u32 k = 0; k < nq; ++k) s.comps |= (u64)(qmask[i * 4 + k] & 0x1FFu) << (9u * k);
+    for (u32 k = 0; k < nq; ++k) s.comps |= (u64)(qmask[k] & 0x1FFu) << (9u * k);
     // root every tree of live edges: grow from the lowest square of each tree
     u32 rooted = 0;
     for (int pass = 0; pass < 9; ++pass) {
@@ -935,10 +941,83 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
     int p1, p2;
     cold_check_win(s, p1, p2);
     s.done = (p1 > 0 || p2 > 0 || s.n > 8u) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
+    u64 *pP, u64 *pQ, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
+    const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Cold s;
+    cold_from_attrs(moves + i * 18, n_moves[i], board + i * 9, qmask + i * 4, n_q[i], s);
     u64 P, Q;
     cold_pack(s, P, Q);
     pP[i] = P;
     pQ[i] = Q;
+}
+
+// Board.make_move / update_qstructs / check_win (board.py:9-115) on caller-assigned attributes, one
+// 64-byte record in, one out (include/qttt.h: qttt_board_op): import -> the SAME step_core the
+// batch kernels run -> export + check_win, in one launch, so that the single-board façade costs one
+// round trip.  The records may live in pinned host memory (the kernel reads and writes them
+// directly).
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void board_op_kernel(const uint8_t *in, uint8_t *out, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    fill_line_lut<QTTT_COLD_BLOCK>(lut);
+    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *r = in + i * QTTT_BOARD_RECORD_BYTES;
+    uint8_t *o = out + i * QTTT_BOARD_RECORD_BYTES;
+    uint8_t mv[18];
+    int8_t bd[9];
+    uint16_t qm[4];
+    for (int k = 0; k < 18; ++k) mv[k] = r[k];
+    for (int k = 0; k < 9; ++k) bd[k] = (int8_t)r[19 + k];
+    for (int k = 0; k < 4; ++k) qm[k] = (uint16_t)(r[30 + 2 * k] | (r[31 + 2 * k] << 8));
+    const u32 op = r[29];
+    Cold s;
+    cold_from_attrs(mv, r[18], bd, qm, r[28], s);
+    u64 P, Q;
+    cold_pack(s, P, Q);
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
+    const u32 n_before = (P1 >> P1_N_SHIFT) & 0xFu;
+    u32 win = 0;
+    if (op != QTTT_OP_CHECK_WIN) win = step_core<false>(P0, P1, Q0, Q1, (u32)r[38] | ((u32)r[39] << 8), r[40] & 1u, lut);
+    const u32 rejected = (op != QTTT_OP_CHECK_WIN && ((P1 >> P1_N_SHIFT) & 0xFu) == n_before) ? 1u : 0u;
+    // update_qstructs alone (board.py:27-69) never autofills: that is make_move's job (board.py:22-25)
+    cold_unpack((u64)P0 | ((u64)P1 << 32), (u64)Q0 | ((u64)Q1 << 32), s, op != QTTT_OP_UPDATE_QSTRUCTS);
+    for (u32 t = 0; t < 9; ++t) {
+        const bool used = t < s.n;
+        const u32 m = s.mv(t);
+        o[t * 2] = used ? (uint8_t)(m & 0xFu) : (uint8_t)255;
+        o[t * 2 + 1] = used ? (uint8_t)(m >> 4) : (uint8_t)255;
+    }
+    o[18] = (uint8_t)s.n;
+    for (u32 v = 0; v < 9; ++v) o[19 + v] = (s.cl >> v & 1u) ? (uint8_t)s.sqv(v) : (uint8_t)0xFF;
+    u32 nq = 0;
+    for (u32 k = 0; k < 4; ++k) {
+        o[30 + 2 * k] = (uint8_t)s.comp(k);
+        o[31 + 2 * k] = (uint8_t)(s.comp(k) >> 8);
+        nq += s.comp(k) != 0u;
+    }
+    o[28] = (uint8_t)nq;
+    o[29] = (uint8_t)op;
+    o[38] = r[38];
+    o[39] = r[39];
+    o[40] = r[40];
+    o[41] = (uint8_t)rejected;
+    int p1, p2;
+    cold_check_win(s, p1, p2);
+    const u32 any = (p1 > 0 || p2 > 0) ? 1u : 0u;
+    const u32 rb = 0x80000000u | (any ? 0x3F800000u : 0u);             // env.py:49: -1.0f / -0.0f
+    o[44] = (uint8_t)rb;
+    o[45] = (uint8_t)(rb >> 8);
+    o[46] = (uint8_t)(rb >> 16);
+    o[47] = (uint8_t)(rb >> 24);
+    o[48] = (uint8_t)((any || s.n > 8u) ? 1u : 0u);                    // env.py:51
+    o[49] = (uint8_t)(int8_t)p1;
+    o[50] = (uint8_t)(int8_t)p2;
+    (void)win;
 }
 
 // legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
@@ -1384,8 +1463,8 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     if (((uintptr_t)q_p1 & 1u) || ((uintptr_t)q_p2 & 7u)) return QTTT_ERR_ACTION;   // 2- / 8-byte LDS row stores
     Planes p = planes(const_cast<void *>(state), n);
     const ObsOut o = {classical, q_p1, q_p1_len, q_p2, q_p2_len, turn};
-    hipLaunchKernelGGL(observe_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.P, p.Q, o, n);
+    hipLaunchKernelGGL(observe_kernel, dim3((unsigned)((n + 2 * QTTT_BLOCK - 1) / (2 * QTTT_BLOCK))), dim3(QTTT_BLOCK), 0,
+                       (hipStream_t)stream, p.P, p.Q, o, n);
     return launch_status();
 }
 
@@ -1418,6 +1497,15 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
     Planes p = planes(state, n);
     hipLaunchKernelGGL(import_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.P, p.Q, moves, n_moves, board, qmask, n_q, n);
+    return launch_status();
+}
+
+int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!records_in || !records_out) return QTTT_ERR_NULL;
+    hipLaunchKernelGGL(board_op_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t *)records_in, (uint8_t *)records_out, n);
     return launch_status();
 }
 

@@ -145,3 +145,72 @@ def test_vecenv_render_and_turn(capsys):
     assert env.turn().tolist() == [1, 0, 1]
     env.render(2)
     assert "+---+---+---+" in capsys.readouterr().out
+
+
+def test_update_qstructs_is_callable_and_is_make_move_minus_append_and_autofill(golden, bits):
+    """board.py:27-69 as a public method of the Board duck type: replaying the golden episodes with
+    the reference's own make_move body (validate, normalise, append — board.py:10-19 — then
+    update_qstructs, then the autofill of board.py:22-25) written out here on the host gives the
+    reference's states."""
+    from qtttgym_amd import Board, QEvalClassic
+    kinds = list(golden["kind"])
+    picks = [i for i, k in enumerate(kinds) if k.startswith("K")] + [i for i, k in enumerate(kinds) if k == "uniform"][:25]
+    T = golden["bits"].shape[1]
+    for e in picks:
+        b = Board(QEvalClassic())
+        for t in range(T):
+            bits.bit = int(golden["bits"][e, t])
+            a, c = (int(x) for x in golden["actions"][e, t])
+            ok = a != c and a < 9 and c < 9 and b.board[a] == -1 and b.board[c] == -1   # board.py:10-15
+            if ok:
+                lo, hi = min(a, c), max(a, c)
+                b.moves.append((lo, hi, len(b.moves)))              # board.py:19
+                b.update_qstructs((lo, hi))                         # board.py:20
+                if b.board.count(-1) == 1:                          # board.py:22-25
+                    idx = b.board.index(-1)
+                    b.board[idx] = len(b.moves)
+                    b.moves.append((idx, idx, len(b.moves)))
+            nm = int(golden["n_moves"][e, t])
+            assert b.board == golden["board"][e, t].tolist(), (e, t)
+            assert b.moves == [(int(golden["moves"][e, t, i, 0]), int(golden["moves"][e, t, i, 1]), i) for i in range(nm)]
+            nq = int(golden["n_q"][e, t])
+            assert b.qstructs == [set(s for s in range(9) if int(golden["qmask"][e, t, i]) >> s & 1) for i in range(nq)]
+    b = Board(QEvalClassic())
+    with pytest.raises(ValueError):
+        b.update_qstructs((0, 1))                                   # not appended to .moves first
+
+
+def test_board_call_is_one_launch_without_copies(bits):
+    """The façade's round trip: attributes -> one pinned 64-byte record -> qttt_board_op -> one
+    pinned record back.  Checked through the C ABI on hand-written records, incl. the op codes."""
+    import torch
+    from qtttgym_amd import _native
+    L = _native.lib()
+    rec_in = torch.zeros(64, dtype=torch.uint8).pin_memory()
+    rec_out = torch.zeros(64, dtype=torch.uint8).pin_memory()
+    a = rec_in.numpy()
+    a[0:18] = 255
+    a[0:2] = (0, 1)                                                  # moves = [(0,1,0)]
+    a[18] = 1
+    a[19:28] = 255                                                   # board = [-1]*9
+    a[28] = 1
+    a[30] = 0b11                                                     # qstructs = [{0,1}]
+    a[38], a[39], a[40] = 1, 0, 1                                    # move (1,0), bit 1 -> lands on hi = 1
+    s = torch.cuda.current_stream()
+    for op in (_native.OP_MAKE_MOVE, _native.OP_UPDATE_QSTRUCTS):
+        a[29] = op
+        assert L.qttt_board_op(rec_in.data_ptr(), rec_out.data_ptr(), 1, s.cuda_stream) == 0
+        s.synchronize()
+        o = rec_out.numpy()
+        assert o[18] == 2 and list(o[0:4]) == [0, 1, 0, 1] and o[41] == 0
+        assert list(o[19:21]) == [0, 1] and all(x == 255 for x in o[21:28]) and o[28] == 0   # K2
+        assert o[48] == 0 and o[49] == 255 and o[50] == 255 and bytes(o[44:48]) == b"\x00\x00\x00\x80"
+    a[29] = _native.OP_CHECK_WIN
+    assert L.qttt_board_op(rec_in.data_ptr(), rec_out.data_ptr(), 1, s.cuda_stream) == 0
+    s.synchronize()
+    assert rec_out.numpy()[18] == 1 and rec_out.numpy()[28] == 1     # nothing moved
+    a[29], a[38], a[39] = _native.OP_MAKE_MOVE, 4, 4                 # same square: rejected, state unchanged
+    assert L.qttt_board_op(rec_in.data_ptr(), rec_out.data_ptr(), 1, s.cuda_stream) == 0
+    s.synchronize()
+    assert rec_out.numpy()[41] == 1 and rec_out.numpy()[18] == 1
+    assert L.qttt_board_op(None, rec_out.data_ptr(), 1, None) == -1 and L.qttt_board_op(None, None, 0, None) == 0

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Wall-clock cost of the single-board façades at N = 1, printed beside the
+reference's own ~12 us per Env.step (measured on one host core).  One JSON line."""
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qtttgym_amd import Env, Board, QEvalClassic  # noqa: E402
+
+
+def episodes(n_steps):
+    rng = random.Random(3)
+    env = Env()
+    env.reset()
+    done_steps = 0
+    t0 = time.perf_counter()
+    while done_steps < n_steps:
+        empty = [i for i, v in enumerate(env._gameboard.board) if v == -1]
+        if len(empty) < 2:
+            env.reset()
+            continue
+        _, _, term, _, _ = env.step(tuple(rng.sample(empty, 2)))
+        done_steps += 1
+        if term:
+            env.reset()
+    return (time.perf_counter() - t0) / done_steps
+
+
+def main():
+    episodes(200)                                            # warm: library load, pinned buffers, kernels
+    t_env = episodes(3000)
+    b = Board(QEvalClassic())
+    b.make_move((0, 1))
+    n = 3000
+    t0 = time.perf_counter()
+    for _ in range(n):
+        b.check_win()
+    t_cw = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for i in range(n):
+        b2 = Board(QEvalClassic())
+        b2.make_move((i % 8, 8))
+    t_mm = (time.perf_counter() - t0) / n
+    print(json.dumps({"row": "facade_latency_N1", "Env.step_us": t_env * 1e6, "Board.make_move_us": t_mm * 1e6,
+                      "Board.check_win_us": t_cw * 1e6, "reference_Env.step_us": 12.0,
+                      "note": "Env.step = make_move + check_win = two qttt_board_op launches + two stream synchronisations"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,7 @@
 """Folds rocprofv3 --pmc counter_collection.csv files (one pass per counter) into
 profiles/pmc_traffic.json, keyed by boards per launch.
 
-    python tools/pmc_summary.py BOARDS fetch_dir write_dir [label]
+    python tools/pmc_summary.py BOARDS fetch_dir write_dir [label] [state_bytes_per_board]
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide
 coalesced read (MI355X_MICROARCH.md §HBM), so it is doubled.  Only the step kernel's
@@ -30,18 +30,20 @@ def mean_counter(d, name):
 def main():
     boards, fetch_dir, write_dir = sys.argv[1], sys.argv[2], sys.argv[3]
     label = sys.argv[4] if len(sys.argv) > 4 else ""
+    state_bytes = int(sys.argv[5]) if len(sys.argv) > 5 else 16
     fetch_kib, nf = mean_counter(fetch_dir, "FETCH_SIZE")
     write_kib, nw = mean_counter(write_dir, "WRITE_SIZE")
     entry = {
         "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB": write_kib,
         "read_bytes": 2 * fetch_kib * 1024, "write_bytes": write_kib * 1024,
         "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
-        "dispatches": [nf, nw], "label": label,
+        "dispatches": [nf, nw], "label": label, "state_bytes_per_board": state_bytes,
+        "algorithmic_bytes_per_launch": (2 * state_bytes + 7) * int(boards),
         "note": "FETCH_SIZE doubled (gfx950 half-count of wide coalesced reads); separate --pmc passes",
     }
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     d = json.load(open(path)) if os.path.exists(path) else {}
-    d[str(boards)] = entry
+    d["%s@%dB" % (boards, state_bytes)] = entry
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(entry))
 

@@ -1,33 +1,44 @@
 #!/usr/bin/env python3
 """Summarises a rocprofv3 --kernel-trace CSV of `bench.py`: the --stats table averages every
-dispatch of the step kernel (recording pass + warm-up + timed region); this prints the same
-kernel's average over the LAST K dispatches (= bench.py's timed region), which is the number
-`roofline.launch_us` must agree with.
+dispatch of the step kernel (recording pass + pilot region + R x (warm-up + timed region)); this
+prints the same kernel's average over the TIMED dispatches only, which is the number bench.py's
+`roofline.launch_us` / `ms_per_step` must agree with.
 
-    python tools/trace_summary.py <dir with *_kernel_trace.csv> K > profiles/rNN/<name>.txt
+    python tools/trace_summary.py <dir with *_kernel_trace.csv> K W R [kernel-substring] > profiles/rNN/<name>.txt
+
+K, W, R = bench.py's --steps, --warmup and the `regions` field of its JSON line: the last
+R * (W + K) dispatches of the kernel are the R regions, the last K of each are timed.
 """
 import csv
 import glob
 import os
+import re
 import sys
 
 
 def main():
-    d, K = sys.argv[1], int(sys.argv[2])
+    d, K, W, R = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    pat = sys.argv[5] if len(sys.argv) > 5 else "step_kernel"
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-    import re; name = re.search(r"step_kernel<[^>]*>", rows[0]["Kernel_Name"]).group(0)
-    print("kernel: %s" % name)
-    print("VGPR_Count=%s SGPR_Count=%s Workgroup_Size=%s Grid_Size=%s" % (
-        rows[-1].get("VGPR_Count"), rows[-1].get("SGPR_Count"), rows[-1].get("Workgroup_Size"),
-        rows[-1].get("Grid_Size")))
-    print("all %d dispatches : avg %.1f ns  min %d  max %d" % (len(dur), sum(dur) / len(dur), min(dur), max(dur)))
-    t = dur[-K:]
-    print("last %d (timed)   : avg %.1f ns  min %d  max %d" % (K, sum(t) / len(t), min(t), max(t)))
-    st = [int(r["Start_Timestamp"]) for r in rows][-K:]
-    en = [int(r["End_Timestamp"]) for r in rows][-K:]
-    print("timed span / K     : %.1f ns" % ((en[-1] - st[0]) / K))
+    name = re.search(r"%s<[^>]*>" % re.escape(pat), rows[-1]["Kernel_Name"])
+    print("kernel: %s" % (name.group(0) if name else rows[-1]["Kernel_Name"][:80]))
+    print("VGPR_Count=%s SGPR_Count=%s LDS_Block_Size=%s Workgroup_Size=%s Grid_Size=%s" % (
+        rows[-1].get("VGPR_Count"), rows[-1].get("SGPR_Count"), rows[-1].get("LDS_Block_Size"),
+        rows[-1].get("Workgroup_Size") or rows[-1].get("Workgroup_Size_X"),
+        rows[-1].get("Grid_Size") or rows[-1].get("Grid_Size_X")))
+    print("all %d dispatches          : avg %.1f ns  min %d  max %d" % (len(dur), sum(dur) / len(dur), min(dur), max(dur)))
+    tail = rows[-R * (W + K):]
+    timed, spans = [], []
+    for r in range(R):
+        reg = tail[r * (W + K) + W:(r + 1) * (W + K)]
+        timed += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in reg]
+        spans.append((int(reg[-1]["End_Timestamp"]) - int(reg[0]["Start_Timestamp"])) / K)
+    spans.sort()
+    print("timed: %d regions x %d      : avg %.1f ns  min %d  max %d" % (R, K, sum(timed) / len(timed), min(timed), max(timed)))
+    print("timed span / K per region  : median %.1f ns  min %.1f  max %.1f" % (spans[len(spans) // 2], spans[0], spans[-1]))
 
 
 if __name__ == "__main__":
