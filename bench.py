@@ -9,12 +9,13 @@ rank (Env.step for every board, auto-reset throughput mode).  Actions are pre-re
 untimed pass of policy kernel + step kernel), the boards are reset, and a timed region replays
 K recorded steps, so it contains env.step and nothing else, with inputs resident in HBM.
 
-Clock.  A region of K launches is short (K = 20 -> 0.16 ms), so the K-launch region is repeated R
-times (R chosen so that the regions add up to >= ~50 ms) and the MEDIAN region is reported.  Each
-region is bracketed by barrier + torch.cuda.synchronize() on both sides and timed twice: by HIP
-events recorded on the launch stream right around the K launches (`value`, `ms_per_step` and
-`roofline` all come from this one clock) and by the host's perf_counter (`host_wall_ms_per_step`,
-reported beside it; it adds the host's launch + synchronise latency, a fixed ~20-60 us per region).
+Clock.  A region of K launches is short (K = 20 -> 0.16 ms), so the region (W untimed warm-up
+steps + K timed steps, bracketed by barrier + torch.cuda.synchronize() on both sides) is repeated
+R times (R chosen so that the timed parts add up to >= ~50 ms) and the MEDIAN region is reported.
+Each region is timed twice: by HIP events recorded on the launch stream right around the K timed
+launches (`value`, `ms_per_step` and `roofline` all come from this one clock) and by the host's
+perf_counter over the whole bracket (`host_wall_ms_per_step` = bracket time / (W + K) launches,
+reported beside it; it adds the host's synchronise latency, a fixed ~20-60 us per region).
 
 Multi-GPU.  Boards are independent: each rank owns B boards (global ids rank*B..), no data-path
 collective; one RCCL all_reduce of episode counters after the timed regions.  `--gpus N` with no
@@ -286,18 +287,23 @@ def run(args):
     ev1 = torch.cuda.Event(enable_timing=True)
 
     def region():
-        """W untimed steps, then EXACTLY K timed steps between barrier + synchronize pairs."""
-        preroll()
+        """One bracket = barrier + synchronize, W untimed steps, EXACTLY K timed steps, synchronize +
+        barrier.  The W warm-up launches are enqueued right in front of the timed ones without a
+        host synchronise in between: the stream is then still busy when the K timed launches are
+        queued, so the HIP events around them read the K kernels back to back — what rocprofv3's
+        kernel trace shows for the same dispatches — and not the host's first-launch latency onto
+        an idle stream (a fixed ~5-15 us per region, 3-10 % at K = 20)."""
         torch.cuda.synchronize(dev)
         barrier()
         t0 = time.perf_counter()
+        preroll()
         ev0.record()
         timed_steps()
         ev1.record()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         barrier()
-        return ev0.elapsed_time(ev1) * 1e-3, t1 - t0
+        return ev0.elapsed_time(ev1) * 1e-3, (t1 - t0) * K / float(K + W)
 
     pilot_ev, _ = region()                                   # also the first-touch / clock ramp pass
     pilot_ev = all_max(pilot_ev)
@@ -329,10 +335,11 @@ def run(args):
             value = B * K * world / ev_med
             achieved = algo_bytes * B / launch_s / 1e9
             bpl = int(os.environ.get("QTTT_STEP_BPL", "2"))
-            kernel = ("step_kernel<%d, false, true, false, %s>" % (bpl, "true" if gym else "false")
+            blk = 1024 if (bpl == 2 and B // 2 >= 512 * 1024) else 512     # qttt_step's own choice (qttt_kernels.hip)
+            kernel = ("step_kernel<%d, %d, false, true, false, %s>" % (blk, bpl, "true" if gym else "false")
                       if args.mode in ("replay", "gym") else
-                      "step_kernel<%d, false, true, true, false>" % bpl if args.mode == "random" else
-                      "sample_actions_kernel + step_kernel<%d, false, true, false, false>" % bpl)
+                      "step_kernel<%d, %d, false, true, true, false>" % (blk, bpl) if args.mode == "random" else
+                      "sample_actions_kernel + step_kernel<%d, %d, false, true, false, false>" % (blk, bpl))
             traffic = None if args.mode != "replay" else pmc_traffic_per_launch(B, state_bytes)
             what = {"replay": "recorded actions replayed (env.step only in the timed region)",
                     "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel)",

@@ -109,12 +109,61 @@ __device__ __forceinline__ V load_stream(const V *p) {
     __builtin_memcpy(&v, &r, sizeof(V));
     return v;
 }
+#ifndef QTTT_STORE_POLICY
+#define QTTT_STORE_POLICY 0      // 0 = nt (product), 1 = sc1, 2 = plain, 3 = sc0 sc1 (experiments, tools/stepbench)
+#endif
 template <typename V>
 __device__ __forceinline__ void store_stream(V *p, const V &v) {
     typedef typename RawOf<sizeof(V)>::type R;
     R r;
     __builtin_memcpy(&r, &v, sizeof(V));
+#if QTTT_STORE_POLICY == 0
     __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+#elif QTTT_STORE_POLICY == 2
+    *reinterpret_cast<R *>(p) = r;
+#else
+#if QTTT_STORE_POLICY == 1
+#define QTTT_ST_MOD " sc1"
+#else
+#define QTTT_ST_MOD " sc0 sc1"
+#endif
+    if constexpr (sizeof(V) == 32) {
+        const u32x4 *h = reinterpret_cast<const u32x4 *>(&r);
+        const u32x4 h0 = h[0], h1 = h[1];
+        asm volatile("global_store_dwordx4 %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(h0) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off offset:16" QTTT_ST_MOD :: "v"(p), "v"(h1) : "memory");
+    } else if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(r) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(r) : "memory");
+    else if constexpr (sizeof(V) == 4) asm volatile("global_store_dword %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(r) : "memory");
+    else if constexpr (sizeof(V) == 2) { const u32 w = r; asm volatile("global_store_short %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(w) : "memory"); }
+    else { const u32 w = r; asm volatile("global_store_byte %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(w) : "memory"); }
+#endif
+}
+
+// Streaming store through a buffer descriptor: block-uniform base (SGPRs) + 32-bit lane offset, so
+// the lane spends no VALU on 64-bit addresses; stores past `bytes` are dropped by the hardware.
+// aux = 2 is the non-temporal hint.  (QTTT_NO_BUFFER_STORE: the flat-address form, for A/B timing.)
+template <typename V>
+__device__ __forceinline__ void store_stream_at(V *base, u32 bytes, u32 index, const V &v) {
+#if defined(QTTT_NO_BUFFER_STORE) || QTTT_STORE_POLICY != 0
+    (void)bytes;
+    store_stream(&base[index], v);
+#else
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x27000);
+    const u32 off = index * (u32)sizeof(V);
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    if constexpr (sizeof(V) == 32) {
+        const u32x4 *h = reinterpret_cast<const u32x4 *>(&r);
+        __builtin_amdgcn_raw_buffer_store_b128(h[0], rs, off, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(h[1], rs, off + 16u, 0, 2);
+    } else if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(r, rs, off, 0, 2);
+    else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(r, rs, off, 0, 2);
+    else if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(r, rs, off, 0, 2);
+    else if constexpr (sizeof(V) == 2) __builtin_amdgcn_raw_buffer_store_b16(r, rs, off, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b8(r, rs, off, 0, 2);
+#endif
 }
 
 __device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
@@ -148,6 +197,15 @@ struct LineLut {
 };
 __constant__ LineLut g_line_lut = LineLut();
 constexpr u32 LINE_LUT_BYTES = 2048;
+// the same table with one entry per dword, for the QTTT_LUT_GLOBAL experiment (lookups served by the
+// vector L1 instead of an LDS copy: no fill, no workgroup barrier)
+struct LineLut4 {
+    uint8_t b[2048];
+    constexpr LineLut4() : b() {
+        for (u32 m = 0; m < 512; ++m) b[4 * m] = mask_has_line(m) ? 0x7F : 0;
+    }
+};
+__device__ const LineLut4 g_line_lut4 = LineLut4();
 
 template <int BLOCK>
 __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
@@ -259,10 +317,11 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
     }
     const u32 a = act & 0xFFu, b = act >> 8;            // action[0], action[1] (env.py:37-38)
     const u32 lo = min(a, b), hi = max(a, b);           // board.py:16-18
-    const u32 pm = (1u << (lo & 31u)) | (1u << (hi & 31u));
-    const u32 cl0 = (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    // the two squares as a mask at the classical mask's place in P1 (only looked at when hi < 9)
+    const u32 pmS = ((1u << P1_CL_SHIFT) << (lo & 31u)) | ((1u << P1_CL_SHIFT) << (hi & 31u));
     // board.py:10-15 (+ IndexError for >8, swallowed at env.py:41): reject before mutating
-    if (hi < 9u && lo != hi && (pm & cl0) == 0u) {
+    if (hi < 9u && lo != hi && (P1 & pmS) == 0u) {
+        const u32 pm = pmS >> P1_CL_SHIFT;
         const u32 n4 = (P1 >> (P1_N_SHIFT - 2u)) & 0x3Cu;            // 4 * moves played (bits 6,7 of P1 are 0)
         u64 comps = (u64)Q1 | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
         const u32 mlo = (u32)(comps >> lo) & SLOT_LSB;   // slot holding lo (board.py:28-33)
@@ -550,13 +609,16 @@ __device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles
 // `actions` when that is not null) — qttt_sample_actions + qttt_step in one launch.
 // OBS: Env.step returns the observation too (env.py:46,53): it is written from the registers the
 // step already holds, through the LDS tiles above — qttt_step + qttt_observe in one launch.
-template <int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
-__global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
+// BLOCK: workgroup size, chosen by the host per launch: 1024 for batches that fill the chip with
+// 1024-thread workgroups (7.2-7.5 us instead of 7.6-7.7 per 1 M boards), QTTT_BLOCK = 512 below
+// (262 144 boards: 3.8 us with 512 against 4.9 with 1024, which would leave half the CUs idle).
+template <int BLOCK, int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
+__global__ __launch_bounds__(BLOCK) void step_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, uint16_t *__restrict__ actions,
     const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi, u32 id_base,
     u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, ObsOut obs, int64_t i_begin,
-    int64_t n_groups) {
-    constexpr u32 TILE_BOARDS = QTTT_BLOCK * BPL;
+    u32 last_groups) {
+    constexpr u32 TILE_BOARDS = BLOCK * BPL;
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
     __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
@@ -568,10 +630,11 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     typedef Vec<u32, BPL> V32;
     typedef Vec<uint16_t, BPL> V16;
     typedef Vec<uint8_t, BPL> V8;
-    const int64_t jb = (int64_t)blockIdx.x * QTTT_BLOCK;                // first lane-group of the block
+    const int64_t jb = (int64_t)blockIdx.x * BLOCK;                // first lane-group of the block
     const int64_t ib = i_begin + jb * BPL;                              // first board of the block
-    const int64_t left = n_groups - jb;                                 // lane-groups left from here on
-    const bool active = (int64_t)threadIdx.x < left;
+    // lane-groups of this block: every block is full except possibly the last one of the grid
+    const u32 ng = blockIdx.x + 1u == gridDim.x ? last_groups : (u32)BLOCK;
+    const bool active = threadIdx.x < ng;
     const u32 g = active ? threadIdx.x : 0u;                            // idle lanes re-read group 0
     // issue all streaming loads first, fill the lookup table while they are in flight
     V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
@@ -580,12 +643,22 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
     V8 bt;
     if (!SAMPLE) act = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g]);
     if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
-    fill_line_lut_nosync<QTTT_BLOCK>(lut);
-    if (SAMPLE) fill_policy_lut<QTTT_BLOCK>(plut);
-    if (OBS) fill_obs_lut<QTTT_BLOCK>(olut);
+#ifdef QTTT_LUT_GLOBAL
+    const uint8_t *lutp = g_line_lut4.b;
+    if (SAMPLE) fill_policy_lut<BLOCK>(plut);
+    if (OBS) fill_obs_lut<BLOCK>(olut);
+    ObsTiles T;
+    if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
+    if (SAMPLE || OBS) __syncthreads();
+#else
+    const uint8_t *lutp = lut;
+    fill_line_lut_nosync<BLOCK>(lut);
+    if (SAMPLE) fill_policy_lut<BLOCK>(plut);
+    if (OBS) fill_obs_lut<BLOCK>(olut);
     ObsTiles T;
     if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
     __syncthreads();
+#endif
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st1 = __builtin_amdgcn_s_memrealtime();
@@ -612,30 +685,29 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_kernel(
                 if (HAS_BITS) bit = bt.v[k] & 1u;
                 else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
             }
-            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
+            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lutp);
             p.v[k] = (u64)P0 | ((u64)P1 << 32);
             q.v[k] = (u64)Q0 | ((u64)Q1 << 32);
             rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f
             tm.v[k] = (uint8_t)(P1 >> 31);
             if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k, olut);
         }
-        store_stream(&reinterpret_cast<V64 *>(pP + ib)[g], p);
-        store_stream(&reinterpret_cast<V64 *>(pQ + ib)[g], q);
-        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g], act);
-        store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g], rw);
-        store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g], tm);
+        store_stream_at(reinterpret_cast<V64 *>(pP + ib), ng * (u32)sizeof(V64), g, p);
+        store_stream_at(reinterpret_cast<V64 *>(pQ + ib), ng * (u32)sizeof(V64), g, q);
+        if (SAMPLE && actions) store_stream_at(reinterpret_cast<V16 *>(actions + ib), ng * (u32)sizeof(V16), g, act);
+        store_stream_at(reinterpret_cast<V32 *>(reward_bits + ib), ng * (u32)sizeof(V32), g, rw);
+        store_stream_at(reinterpret_cast<V8 *>(terminated + ib), ng * (u32)sizeof(V8), g, tm);
     }
     if (OBS) {
         __syncthreads();
-        const u32 valid = (u32)min((int64_t)QTTT_BLOCK, left) * BPL;
-        obs_copy_out<QTTT_BLOCK, TILE_BOARDS>(otile, obs, ib, valid);
+        obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, ib, ng * BPL);
     }
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st2 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st3 = __builtin_amdgcn_s_memrealtime();
     if (g_debug_stamps && (threadIdx.x & 63) == 0) {
-        u64 *o = g_debug_stamps + ((int64_t)blockIdx.x * (QTTT_BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+        u64 *o = g_debug_stamps + ((int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 4;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
     }
 #endif
@@ -1261,7 +1333,9 @@ inline int &tuning_bpl() {
 
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
 inline int cold_grid_for(int64_t n) { return (int)((n + QTTT_COLD_BLOCK - 1) / QTTT_COLD_BLOCK); }
-inline int step_grid_for(int64_t n_groups) { return (int)((n_groups + QTTT_BLOCK - 1) / QTTT_BLOCK); }
+inline int blocks_for(int64_t n_groups, int block) { return (int)((n_groups + block - 1) / block); }
+// lane-groups from which qttt_step uses 1024-thread workgroups: 512 such workgroups = 16 waves on every SIMD pair
+#define QTTT_BIG_BLOCK_MIN_GROUPS (512 * 1024)
 
 inline int launch_status() {
     hipError_t e = hipGetLastError();
@@ -1329,10 +1403,16 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     };
     while (bpl_max > 1 && !aligned(bpl_max)) bpl_max >>= 1;
     const ObsOut oo = obs ? *obs : ObsOut{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-#define QTTT_LAUNCH(BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                              \
-    hipLaunchKernelGGL((step_kernel<BPL, HB, AR, SM, OB>), dim3(step_grid_for(NG)), dim3(QTTT_BLOCK), 0, s, \
+#define QTTT_LAUNCH_B(BLK, BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                        \
+    hipLaunchKernelGGL((step_kernel<BLK, BPL, HB, AR, SM, OB>), dim3(blocks_for(NG, BLK)), dim3(BLK), 0, s, \
                        p.P, p.Q, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated, oo,         \
-                       (int64_t)(I0), (int64_t)(NG))
+                       (int64_t)(I0), (u32)((NG) - (int64_t)(blocks_for(NG, BLK) - 1) * (BLK)))
+    // workgroup size: 1024 threads once that still gives every CU two workgroups' worth of waves
+#define QTTT_LAUNCH(BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                              \
+    do {                                                                                              \
+        if ((BPL) == 2 && (NG) >= (int64_t)QTTT_BIG_BLOCK_MIN_GROUPS) QTTT_LAUNCH_B(1024, 2, HB, AR, SM, OB, I0, NG, KF, IDB); \
+        else QTTT_LAUNCH_B(QTTT_BLOCK, BPL, HB, AR, SM, OB, I0, NG, KF, IDB);                          \
+    } while (0)
 #define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                                                           \
     do {                                                                                              \
         if (obs) {                                                                                    \
@@ -1367,6 +1447,7 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     }
 #undef QTTT_DISPATCH
 #undef QTTT_LAUNCH
+#undef QTTT_LAUNCH_B
     return launch_status();
 }
 
