@@ -140,32 +140,6 @@ __device__ __forceinline__ void store_stream(V *p, const V &v) {
 #endif
 }
 
-// Streaming store through a buffer descriptor: block-uniform base (SGPRs) + 32-bit lane offset, so
-// the lane spends no VALU on 64-bit addresses; stores past `bytes` are dropped by the hardware.
-// aux = 2 is the non-temporal hint.  (QTTT_NO_BUFFER_STORE: the flat-address form, for A/B timing.)
-template <typename V>
-__device__ __forceinline__ void store_stream_at(V *base, u32 bytes, u32 index, const V &v) {
-#if defined(QTTT_NO_BUFFER_STORE) || QTTT_STORE_POLICY != 0
-    (void)bytes;
-    store_stream(&base[index], v);
-#else
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x27000);
-    const u32 off = index * (u32)sizeof(V);
-    typedef typename RawOf<sizeof(V)>::type R;
-    R r;
-    __builtin_memcpy(&r, &v, sizeof(V));
-    if constexpr (sizeof(V) == 32) {
-        const u32x4 *h = reinterpret_cast<const u32x4 *>(&r);
-        __builtin_amdgcn_raw_buffer_store_b128(h[0], rs, off, 0, 2);
-        __builtin_amdgcn_raw_buffer_store_b128(h[1], rs, off + 16u, 0, 2);
-    } else if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(r, rs, off, 0, 2);
-    else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(r, rs, off, 0, 2);
-    else if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(r, rs, off, 0, 2);
-    else if constexpr (sizeof(V) == 2) __builtin_amdgcn_raw_buffer_store_b16(r, rs, off, 0, 2);
-    else __builtin_amdgcn_raw_buffer_store_b8(r, rs, off, 0, 2);
-#endif
-}
-
 __device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
 // v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xFFFFFFFF for 0
 __device__ __forceinline__ u32 ffbl_raw(u32 x) {
@@ -692,11 +666,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
             tm.v[k] = (uint8_t)(P1 >> 31);
             if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k, olut);
         }
-        store_stream_at(reinterpret_cast<V64 *>(pP + ib), ng * (u32)sizeof(V64), g, p);
-        store_stream_at(reinterpret_cast<V64 *>(pQ + ib), ng * (u32)sizeof(V64), g, q);
-        if (SAMPLE && actions) store_stream_at(reinterpret_cast<V16 *>(actions + ib), ng * (u32)sizeof(V16), g, act);
-        store_stream_at(reinterpret_cast<V32 *>(reward_bits + ib), ng * (u32)sizeof(V32), g, rw);
-        store_stream_at(reinterpret_cast<V8 *>(terminated + ib), ng * (u32)sizeof(V8), g, tm);
+        store_stream(&reinterpret_cast<V64 *>(pP + ib)[g], p);
+        store_stream(&reinterpret_cast<V64 *>(pQ + ib)[g], q);
+        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g], act);
+        store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g], rw);
+        store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g], tm);
     }
     if (OBS) {
         __syncthreads();
@@ -902,6 +876,135 @@ __device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) 
     if (p2 >= 10) p2 = -1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The MCTS-side kernels (node_info / expand / rollout / check_win) do not go through the generic
+// `Cold` form: what they need is computed straight from the packed words.
+struct Lite {
+    u64 P;          // plane P with the implicit autofill materialised in the nibbles
+    u32 cl;         // classical mask, autofilled square included
+    u32 n;          // len(moves), autofill move included
+    u32 n_real;     // moves played (the autofill move is not one)
+};
+
+__device__ __forceinline__ Lite lite_unpack(u64 P) {
+    Lite s;
+    const u32 P1 = (u32)(P >> 32);
+    s.cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    s.n_real = s.n = (P1 >> P1_N_SHIFT) & 0xFu;
+    if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {                 // board.py:22-25, implicit in the state
+        const u32 idx = (u32)__builtin_ctz(~s.cl);
+        P |= (u64)(15u - s.n) << (4u * idx + 2u);                    // its code was 0 (isolated square)
+        s.cl = 0x1FFu;
+        s.n += 1u;
+    }
+    s.P = P;
+    return s;
+}
+
+// Board.check_win (board.py:71-115) without visiting lines: p1_round = min over completed X lines of
+// the line's latest round = the smallest m in {4,6,8} such that the X squares of round <= m contain
+// a line (three X marks need rounds 0,2,4 at least); likewise p2_round over {5,7}.  "round <= m" is
+// "code >= 15-m" on the complemented nibbles, tested for eight squares at once (classical codes are
+// 7..15: bit 3 set and low three bits >= T-8 <=> adding 16-T carries into bit 3).
+__device__ __forceinline__ void fast_check_win(const Lite &s, int &p1, int &p2) {
+    const u32 W = (u32)(s.P >> 2);                                   // codes of squares 0..7
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+    const u32 par = W & 0x11111111u;                                 // odd code = even round = X
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((c8 & 1u) << 8);
+    const u32 X = s.cl & even, O = s.cl & ~even;
+    u32 ge[3];
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k) {                                    // code >= 9, 10, 11  <=>  round <= 6, 5, 4
+        const u32 T = 9u + k;
+        const u32 y = ((W & 0x77777777u) + 0x11111111u * (16u - T)) & W & 0x88888888u;
+        ge[k] = ((__builtin_amdgcn_udot8(y, 0x00008421u, 0u, false) |
+                  (__builtin_amdgcn_udot8(y, 0x84210000u, 0u, false) << 4)) >> 3) | ((c8 >= T ? 1u : 0u) << 8);
+    }
+    const uint8_t *lut = g_line_lut.b;
+    p1 = lut[X & ge[2]] ? 4 : (lut[X & ge[0]] ? 6 : (lut[X] ? 8 : -1));
+    p2 = lut[O & ge[1]] ? 5 : (lut[O] ? 7 : -1);
+}
+
+// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal
+__device__ __forceinline__ void fast_update_winner(const Lite &s, int &winner, int &terminal) {
+    int p1, p2;
+    fast_check_win(s, p1, p2);
+    winner = -1;
+    terminal = 0;
+    if (p1 > 0 && p2 > 0) { winner = p1 < p2; terminal = 1; }
+    else if (p2 < 0 && p1 > 0) { winner = 1; terminal = 1; }
+    else if (p1 < 0 && p2 > 0) { winner = 0; terminal = 1; }
+    terminal = (s.n == 9u) || terminal;
+}
+
+// GameState.actions (mcts.py:20-27) in ind2move order (mcts.py:339-343): the pairs (i, j > i) of
+// row i are the empty squares above i, eight rows at offsets 0, 8, 15, 21, 26, 30, 33, 35
+__device__ __forceinline__ u64 fast_legal_mask(u32 cl) {
+    const u32 E = ~cl & 0x1FFu;
+    u64 m = 0;
+    u32 off = 0;
+#pragma unroll
+    for (u32 i = 0; i < 8; ++i) {
+        m |= (u64)((E >> i & 1u) ? (E >> (i + 1u)) : 0u) << off;
+        off += 8u - i;
+    }
+    return m;
+}
+
+// GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
+// (Objects/tupleobject.c tuplehash, xxHash-style; hash(int) = the int, hash(-1) = -2).  One
+// accumulator step is acc = rotl(acc + lane * P2, 31) * P1; the products lane * P2 are tabulated
+// for the ten board values and for the hash of every possible move tuple (lo, hi, round).
+constexpr u64 PYH_P1 = 11400714785074694791ull, PYH_P2 = 14029467366897019727ull, PYH_P5 = 2870177450012600261ull;
+__host__ __device__ constexpr u64 pyh_step(u64 acc, u64 lane_times_p2) {
+    acc += lane_times_p2;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * PYH_P1;
+}
+__host__ __device__ constexpr u64 pyh_fin(u64 acc, u64 len) {
+    acc += len ^ (PYH_P5 ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+struct PyHashLut {
+    u64 board[10];          // [v + 1] for Board.board value v = -1..8
+    u64 move[9][9][9];      // [lo][hi][round]
+    constexpr PyHashLut() : board(), move() {
+        board[0] = (u64)(long long)-2 * PYH_P2;
+        for (u64 v = 0; v < 9; ++v) board[v + 1] = v * PYH_P2;
+        for (u64 a = 0; a < 9; ++a)
+            for (u64 b = 0; b < 9; ++b)
+                for (u64 t = 0; t < 9; ++t) {
+                    u64 in = PYH_P5;
+                    in = pyh_step(in, a * PYH_P2);
+                    in = pyh_step(in, b * PYH_P2);
+                    in = pyh_step(in, t * PYH_P2);
+                    move[a][b][t] = pyh_fin(in, 3) * PYH_P2;
+                }
+    }
+};
+__device__ const PyHashLut g_pyhash_lut = PyHashLut();
+
+__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0) {
+    u64 acc = PYH_P5;
+    // holders of every round: nibble (code - 7) of H = square + 1 (code 0 = no move lands in nibble 9)
+    u64 H = 0;
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) {
+        const u32 c = (u32)(s.P >> (4u * v + 2u)) & 0xFu;
+        acc = pyh_step(acc, g_pyhash_lut.board[(s.cl >> v & 1u) ? 16u - c : 0u]);   // value = 15 - c
+        H |= (u64)(v + 1u) << ((4u * c + 36u) & 63u);
+    }
+    for (u32 t = 0; t < s.n; ++t) {
+        const u32 h = (u32)(H >> (4u * (8u - t))) & 0xFu;
+        const u32 c = h ? h - 1u : 0u;                              // the square that holds round t
+        const u32 x = (t >= s.n_real) ? 0u : cold_move_x(Q0, P1_stored, s.n_real, t);   // autofill = (idx, idx)
+        const u32 o = min(c ^ x, 8u);                               // (only a corrupted import could exceed 8)
+        acc = pyh_step(acc, g_pyhash_lut.move[min(c, o)][max(c, o)][t]);
+    }
+    return (int64_t)pyh_fin(acc, 9u + s.n);
+}
+
 #define QTTT_COLD_BLOCK 256
 
 // Env._observation (env.py:68-85) of stored boards: two boards per lane (one 16-byte load per
@@ -937,10 +1040,10 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
     const u64 *pP, const u64 *pQ, int8_t *p1_round, int8_t *p2_round, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Cold s;
-    cold_unpack(pP[i], pQ[i], s);
+    (void)pQ;
+    const Lite s = lite_unpack(load_stream(&pP[i]));
     int p1, p2;
-    cold_check_win(s, p1, p2);
+    fast_check_win(s, p1, p2);
     p1_round[i] = (int8_t)p1;
     p2_round[i] = (int8_t)p2;
 }
@@ -1124,66 +1227,19 @@ struct PairLut {
 };
 __constant__ PairLut g_pair_lut = PairLut();
 
-// GameState.actions (mcts.py:20-27): action a is listed iff both its squares are classical-empty
-__device__ __forceinline__ u64 cold_legal_mask(const Cold &s) {
-    u64 m = 0;
-    for (int a = 0; a < 36; ++a) {
-        const u32 pr = g_pair_lut.b[a];
-        if (!((s.cl >> (pr & 0xFu)) & 1u) && !((s.cl >> (pr >> 4)) & 1u)) m |= 1ull << a;
-    }
-    return m;
-}
-
-// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal
-__device__ __forceinline__ void cold_update_winner(const Cold &s, int &winner, int &terminal) {
-    int p1, p2;
-    cold_check_win(s, p1, p2);
-    winner = -1;
-    terminal = 0;
-    if (p1 > 0 && p2 > 0) { winner = p1 < p2; terminal = 1; }
-    else if (p2 < 0 && p1 > 0) { winner = 1; terminal = 1; }
-    else if (p1 < 0 && p2 > 0) { winner = 0; terminal = 1; }
-    terminal = (s.n == 9u) || terminal;
-}
-
-// GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
-// (Objects/tupleobject.c tuplehash, xxHash-style; hash(int) = the int, hash(-1) = -2).
-__device__ inline u64 py_tuple_acc(u64 acc, u64 lane) {
-    acc += lane * 14029467366897019727ull;
-    acc = (acc << 31) | (acc >> 33);
-    return acc * 11400714785074694791ull;
-}
-__device__ inline u64 py_tuple_fin(u64 acc, u64 len) {
-    acc += len ^ (2870177450012600261ull ^ 3527539ull);
-    return acc == ~0ull ? 1546275796ull : acc;
-}
-__device__ __forceinline__ int64_t cold_py_hash(const Cold &s) {
-    u64 acc = 2870177450012600261ull;
-    for (u32 v = 0; v < 9; ++v)
-        acc = py_tuple_acc(acc, (s.cl >> v & 1u) ? (u64)s.sqv(v) : (u64)(int64_t)-2);
-    for (u32 t = 0; t < s.n; ++t) {
-        u64 in = 2870177450012600261ull;
-        in = py_tuple_acc(in, (u64)(s.mv(t) & 0xFu));
-        in = py_tuple_acc(in, (u64)(s.mv(t) >> 4));
-        in = py_tuple_acc(in, (u64)t);
-        acc = py_tuple_acc(acc, py_tuple_fin(in, 3));
-    }
-    return (int64_t)py_tuple_fin(acc, 9u + s.n);
-}
-
 __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Cold s;
-    cold_unpack(pP[i], pQ[i], s);
+    const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
+    const Lite s = lite_unpack(P);
     int w, t;
-    cold_update_winner(s, w, t);
+    fast_update_winner(s, w, t);
     winner[i] = (int8_t)w;
     terminal[i] = (uint8_t)t;
-    legal[i] = cold_legal_mask(s);
-    key[i] = cold_py_hash(s);
+    legal[i] = fast_legal_mask(s.cl);
+    key[i] = fast_py_hash(s, (u32)(P >> 32), (u32)Q);
 }
 
 // MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
@@ -1220,11 +1276,10 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
         u64 lm = 0;
         int64_t k = 0;
         if (c < kids) {
-            Cold s;
-            cold_unpack(kidP[c], kidQ[c], s);
-            cold_update_winner(s, w, t);
-            lm = cold_legal_mask(s);
-            k = cold_py_hash(s);
+            const Lite s = lite_unpack(kidP[c]);
+            fast_update_winner(s, w, t);
+            lm = fast_legal_mask(s.cl);
+            k = fast_py_hash(s, (u32)(kidP[c] >> 32), (u32)kidQ[c]);
         }
         winner[i * 2 + c] = (int8_t)w;
         terminal[i * 2 + c] = (uint8_t)t;
@@ -1259,10 +1314,8 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
         played += 1u;
     }
     const u64 oP = (u64)P0 | ((u64)P1 << 32), oQ = (u64)Q0 | ((u64)Q1 << 32);
-    Cold s;
-    cold_unpack(oP, oQ, s);
     int w, t;
-    cold_update_winner(s, w, t);
+    fast_update_winner(lite_unpack(oP), w, t);
     result[i] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));       // MCTS._reward, mcts.py:200-209
     plies[i] = (uint8_t)played;
     if (fP) { fP[i] = oP; fQ[i] = oQ; }
@@ -1301,7 +1354,7 @@ __global__ __launch_bounds__(QTTT_ENC_BLOCK) void encode_kernel(
             }
         }
         if (mask && part == 3u) {                                  // the lightest part also does the mask
-            const u64 lm = cold_legal_mask(s);
+            const u64 lm = fast_legal_mask(s.cl);
             for (int a = 0; a < 36; ++a) mtile[b * 36 + a] = (uint8_t)(lm >> a & 1ull);
         }
     }
