@@ -302,9 +302,11 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
         const u32 mhi = (u32)(comps >> hi) & SLOT_LSB;   // slot holding hi (board.py:35-40)
         const bool has_lo = mlo != 0u;
         const bool cyc = (mlo & mhi) != 0u;              // board.py:42: same component -> cycle
-        // x: the square that becomes the child end of the new edge; on a cycle it is the square
-        // the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi), which becomes the root
-        const u32 x4 = ((cyc && bit == 0u) ? lo : hi) * 4u;
+        // x: the square that becomes the child end of the new edge (its tree is re-rooted at it).
+        // On a cycle it is the square the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi);
+        // otherwise either end will do, and an isolated square is the cheap one: hi, unless only lo
+        // is isolated (no walk at all instead of a walk up hi's tree)
+        const u32 x4 = (((cyc && bit == 0u) || (!has_lo && mhi != 0u)) ? lo : hi) * 4u;
         u64 P = (u64)P0 | ((u64)P1 << 32);
         {   // re-root x's tree at x: reverse the parent edges along the path x -> old root.
             // All quantities are "times four": v4 = 4v is the shift that brings square v's nibble
@@ -330,7 +332,7 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
         // nibble of Q0 (x*4 rotated right by 4n+4, i.e. x<<16 rotated by 4n+18), every move to the
         // `last x` field; n += 1.
         const u32 x16 = (a ^ b) << 16;
-        Q0 ^= rotr32(x16, n4 + 18u);
+        Q0 ^= rotr32(x16, (P1 >> (P1_N_SHIFT - 2u)) + 18u);            // a rotate only looks at the low five bits
         P1 = ((P1 & ~(0xFu << P1_LX_SHIFT)) | x16) + (1u << P1_N_SHIFT);
         // ---- board.py:42-69 on the cached qstructs, all cases in one straight line ----
         // ffbl_raw(0) = -1, a 64-bit shift by -1 (= 63) gives 0: c1 = component of hi, 0 if none

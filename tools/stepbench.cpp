@@ -142,7 +142,8 @@ int main(int argc, char **argv) {
     u64 *pA = (u64 *)state; int64_t stride = (n + 63) & ~63ll; u64 *pB = pA + stride; u32 *pC = (u32 *)(pB + stride);
     std::vector<float> fl[3], fl16;
     for (int r = 0; r < reps; ++r) {
-        for (auto &L : libs) {
+        for (size_t li = 0; li < libs.size(); ++li) {
+            Lib &L = libs[(li + (size_t)r) % libs.size()];      // rotate the order: the slot after the floor kernels is slower
             L.set_tuning(L.bpl, L.pipe);
             L.reset(state, n, s);
             L.step_many(state, actions, nullptr, seed, 0, 0, 1, reward, term, 0, n, W, s);
