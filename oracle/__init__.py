@@ -3,7 +3,8 @@
 ctypes/numpy front end to ``libqttt_oracle.so`` (oracle/qttt_oracle.c), the CPU restatement
 of the reference's ``Env.step`` path.  Importers allowed: ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``.  The product
-package ``qtttgym_amd`` must never import this module (tests/test_no_oracle_in_product.py).
+package ``qtttgym_amd`` must never import this module
+(tests/test_abi_and_host.py::test_product_never_imports_the_oracle).
 """
 import ctypes
 import os

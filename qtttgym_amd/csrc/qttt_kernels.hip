@@ -171,15 +171,6 @@ struct LineLut {
 };
 __constant__ LineLut g_line_lut = LineLut();
 constexpr u32 LINE_LUT_BYTES = 2048;
-// the same table with one entry per dword, for the QTTT_LUT_GLOBAL experiment (lookups served by the
-// vector L1 instead of an LDS copy: no fill, no workgroup barrier)
-struct LineLut4 {
-    uint8_t b[2048];
-    constexpr LineLut4() : b() {
-        for (u32 m = 0; m < 512; ++m) b[4 * m] = mask_has_line(m) ? 0x7F : 0;
-    }
-};
-__device__ const LineLut4 g_line_lut4 = LineLut4();
 
 template <int BLOCK>
 __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
@@ -619,22 +610,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     V8 bt;
     if (!SAMPLE) act = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g]);
     if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
-#ifdef QTTT_LUT_GLOBAL
-    const uint8_t *lutp = g_line_lut4.b;
-    if (SAMPLE) fill_policy_lut<BLOCK>(plut);
-    if (OBS) fill_obs_lut<BLOCK>(olut);
-    ObsTiles T;
-    if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
-    if (SAMPLE || OBS) __syncthreads();
-#else
-    const uint8_t *lutp = lut;
     fill_line_lut_nosync<BLOCK>(lut);
     if (SAMPLE) fill_policy_lut<BLOCK>(plut);
     if (OBS) fill_obs_lut<BLOCK>(olut);
     ObsTiles T;
     if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
     __syncthreads();
-#endif
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u64 st1 = __builtin_amdgcn_s_memrealtime();
@@ -661,7 +642,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
                 if (HAS_BITS) bit = bt.v[k] & 1u;
                 else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
             }
-            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lutp);
+            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
             p.v[k] = (u64)P0 | ((u64)P1 << 32);
             q.v[k] = (u64)Q0 | ((u64)Q1 << 32);
             rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f
@@ -765,7 +746,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
 // Friendly unpacked form for the kernels that are not on the hot path.  Everything is kept in
 // packed words with shift accessors — no per-thread arrays: runtime-indexed arrays would live in
 // scratch memory, and the scratch-backed version of these kernels returned an occasional wrong
-// element under 512-thread workgroups on this part (tools/flake_probe.py).
+// element under 512-thread workgroups on this part (round 1).
 // tests/test_abi_and_host.py asserts that no kernel of this file uses scratch.
 struct Cold {
     u32 n;          // n_moves, autofill move included

@@ -92,7 +92,7 @@ def test_oracle_ind2move_table():
 def test_no_kernel_uses_scratch_memory():
     """Every kernel keeps its working set in registers / LDS: private (scratch) memory is both slow
     and the one thing that ever produced a wrong element here (runtime-indexed per-thread arrays
-    under 512-thread workgroups, tools/flake_probe.py).  Checked from the compiler's own report."""
+    under 512-thread workgroups in round 1).  Checked from the compiler's own report."""
     import subprocess
     src = os.path.join(ROOT, "qtttgym_amd", "csrc", "qttt_kernels.hip")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
