@@ -369,7 +369,7 @@ def run(args):
                              "algorithmic_bytes_per_board_step": algo_bytes,
                              "algorithmic_bytes_per_launch": algo_bytes * B},
             }
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:                 # rank 0 at N = 1 only
                 # bounded sample: the first <=256 recorded steps of every board of rank 0, ~12 s of CPU
                 t_cpu = min(T, 256)
                 out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed, args.cpu_budget)

@@ -967,15 +967,24 @@ struct PyHashLut {
     }
 };
 __device__ const PyHashLut g_pyhash_lut = PyHashLut();
+constexpr u32 PYHASH_LUT_WORDS = 10 + 729;          // u64 entries: board[10] then move[9][9][9]
 
-__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0) {
+// the table is gathered 9 + n times per board with a different entry in every lane: it is served
+// from an LDS copy (5.9 KB per workgroup), not from the vector cache
+template <int BLOCK>
+__device__ inline void fill_pyhash_lut(u64 *dst) {
+    const u64 *src = reinterpret_cast<const u64 *>(&g_pyhash_lut);
+    for (u32 w = threadIdx.x; w < PYHASH_LUT_WORDS; w += BLOCK) dst[w] = src[w];
+}
+
+__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0, const u64 *tbl) {
     u64 acc = PYH_P5;
     // holders of every round: nibble (code - 7) of H = square + 1 (code 0 = no move lands in nibble 9)
     u64 H = 0;
 #pragma unroll
     for (u32 v = 0; v < 9; ++v) {
         const u32 c = (u32)(s.P >> (4u * v + 2u)) & 0xFu;
-        acc = pyh_step(acc, g_pyhash_lut.board[(s.cl >> v & 1u) ? 16u - c : 0u]);   // value = 15 - c
+        acc = pyh_step(acc, tbl[(s.cl >> v & 1u) ? 16u - c : 0u]);   // board[value + 1], value = 15 - c
         H |= (u64)(v + 1u) << ((4u * c + 36u) & 63u);
     }
     for (u32 t = 0; t < s.n; ++t) {
@@ -983,7 +992,7 @@ __device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u3
         const u32 c = h ? h - 1u : 0u;                              // the square that holds round t
         const u32 x = (t >= s.n_real) ? 0u : cold_move_x(Q0, P1_stored, s.n_real, t);   // autofill = (idx, idx)
         const u32 o = min(c ^ x, 8u);                               // (only a corrupted import could exceed 8)
-        acc = pyh_step(acc, g_pyhash_lut.move[min(c, o)][max(c, o)][t]);
+        acc = pyh_step(acc, tbl[10u + (min(c, o) * 9u + max(c, o)) * 9u + t]);   // move[lo][hi][t]
     }
     return (int64_t)pyh_fin(acc, 9u + s.n);
 }
@@ -1213,6 +1222,9 @@ __constant__ PairLut g_pair_lut = PairLut();
 __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
+    __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    fill_pyhash_lut<QTTT_BLOCK>(htbl);
+    __syncthreads();
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
@@ -1222,7 +1234,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     winner[i] = (int8_t)w;
     terminal[i] = (uint8_t)t;
     legal[i] = fast_legal_mask(s.cl);
-    key[i] = fast_py_hash(s, (u32)(P >> 32), (u32)Q);
+    key[i] = fast_py_hash(s, (u32)(P >> 32), (u32)Q, htbl);
 }
 
 // MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
@@ -1232,7 +1244,9 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
     u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, uint8_t *n_children,
     int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    fill_line_lut<QTTT_BLOCK>(lut);
+    __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    fill_pyhash_lut<QTTT_BLOCK>(htbl);
+    fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const u64 P = pP[i], Q = pQ[i];
@@ -1262,7 +1276,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
             const Lite s = lite_unpack(kidP[c]);
             fast_update_winner(s, w, t);
             lm = fast_legal_mask(s.cl);
-            k = fast_py_hash(s, (u32)(kidP[c] >> 32), (u32)kidQ[c]);
+            k = fast_py_hash(s, (u32)(kidP[c] >> 32), (u32)kidQ[c], htbl);
         }
         winner[i * 2 + c] = (int8_t)w;
         terminal[i * 2 + c] = (uint8_t)t;

@@ -104,3 +104,23 @@ def test_no_kernel_uses_scratch_memory():
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
     assert len(names) == len(scratch) and len(names) >= 25
     assert all(v == 0 for v in scratch), [n for n, v in zip(names, scratch) if v]
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """bench.py --gpus 2 with no launcher starts its own two ranks without importing torch in the
+    parent; here (no GPU in the build container, or both ranks on RCCL with one GPU) every rank refuses
+    to run, and the parent must come back with that failure instead of hanging or printing a line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the two ranks would simply run")
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "QTTT_DIST_BACKEND"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--boards", "64",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=300, env=e)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "no HIP device visible" in out.stderr or "needs 2 GPUs" in out.stderr

@@ -87,3 +87,26 @@ def test_bench_refuses_more_ranks_than_gpus_on_rccl():
                          timeout=600, env=e)
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_under_torchrun_two_ranks():
+    """The driver's own launch line for N > 1: python -m torch.distributed.run ... bench.py --gpus 2
+    (ranks from the environment, no self-launch), here with both ranks on the one GPU over gloo."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    e = dict(os.environ, QTTT_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--boards", "16384", "--steps", "10", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["self_launched"] is False
+    assert "cpu_baseline" not in d                                      # rank 0 at N = 1 only

@@ -123,11 +123,14 @@ def test_full_size_one_million_boards_vs_oracle():
     assert n_term > n  # every board finished at least one episode on average
 
 
-def test_export_import_round_trip_continues_identically():
+@pytest.mark.parametrize("pre_steps", [5, 8, 9])
+def test_export_import_round_trip_continues_identically(pre_steps):
+    """Board attributes out and back in (qttt_export -> qttt_import) at mid-game and at the end of
+    the game (nine real moves, implicit autofill, finished boards), then both continue identically."""
     from qtttgym_amd import VecEnv
     n = 4096
     env = VecEnv(n, seed=11)
-    for t in range(5):
+    for t in range(pre_steps):
         env.step_raw(env.sample_actions())
     ex = env.export_boards()
     env2 = VecEnv(n, seed=11)
