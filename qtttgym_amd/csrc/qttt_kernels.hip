@@ -174,7 +174,11 @@ constexpr u32 LINE_LUT_BYTES = 2048;
 
 template <int BLOCK>
 __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
+#ifdef QTTT_LUT_COMPUTE      // experiment: no global load in front of the workgroup barrier
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = mask_has_line(w) ? 0x7Fu : 0u;
+#else
     for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = g_line_lut.b[w];
+#endif
 }
 template <int BLOCK>
 __device__ inline void fill_line_lut(uint8_t *lut) {
