@@ -172,13 +172,21 @@ struct LineLut {
 __constant__ LineLut g_line_lut = LineLut();
 constexpr u32 LINE_LUT_BYTES = 2048;
 
+// The LDS copy is COMPUTED (thread w makes entry w, a dozen instructions once per launch), not
+// loaded: a global load in front of the workgroup barrier would tie the barrier — and with it every
+// wave of the workgroup — to the slowest wave's state loads (its `s_waitcnt vmcnt(0)` covers them
+// too).  Computed, the barrier is passed while the loads are still in flight and every wave then
+// waits for its own data only: 7.2 – 7.4 against 7.45 – 7.6 us per 1 M boards, 3.8 against 4.05 us
+// at 262 144 (tools/stepbench, interleaved).
+__device__ __forceinline__ u32 line_lut_entry(u32 m) {
+    const u32 rows = m & (m >> 1) & (m >> 2) & 0x049u;                 // 0-1-2, 3-4-5, 6-7-8
+    const u32 cols = m & (m >> 3) & (m >> 6) & 0x007u;                 // 0-3-6, 1-4-7, 2-5-8
+    const bool diag = (m & 0x111u) == 0x111u || (m & 0x054u) == 0x054u;
+    return ((rows | cols) != 0u || diag) ? 0x7Fu : 0u;
+}
 template <int BLOCK>
 __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
-#ifdef QTTT_LUT_COMPUTE      // experiment: no global load in front of the workgroup barrier
-    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = mask_has_line(w) ? 0x7Fu : 0u;
-#else
-    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = g_line_lut.b[w];
-#endif
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = line_lut_entry(w);
 }
 template <int BLOCK>
 __device__ inline void fill_line_lut(uint8_t *lut) {
@@ -474,12 +482,6 @@ struct ObsLut {
 __constant__ ObsLut g_obs_lut = ObsLut();
 constexpr u32 OBS_LUT_BYTES = 128;
 
-template <int BLOCK>
-__device__ inline void fill_obs_lut(u32 *dst) {
-    const u32 *src = &g_obs_lut.sel[0][0];
-    for (u32 w = threadIdx.x; w < 32u; w += BLOCK) dst[w] = src[w];
-}
-
 // One move list of the observation.  h: byte j = holder square + 1 of the candidate move j (0 =
 // not live), x: byte j = lo^hi of that move.  Returns the (lo,hi) pairs of the live moves in move
 // order as w0 | w1 (two pairs each, 0xFF-padded) and their number.
@@ -607,7 +609,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     const u32 ng = blockIdx.x + 1u == gridDim.x ? last_groups : (u32)BLOCK;
     const bool active = threadIdx.x < ng;
     const u32 g = active ? threadIdx.x : 0u;                            // idle lanes re-read group 0
-    // issue all streaming loads first, fill the lookup table while they are in flight
+    // The small tables that are LOADED (policy, observation) are requested first and stored after
+    // the streaming loads have been issued: vector loads return in order, so the wait in front of
+    // the table's LDS store then covers the table word only, not this wave's state.  The line table
+    // is computed.  Either way the workgroup barrier is passed while the state is still in flight.
+    static_assert(!SAMPLE || BLOCK >= (int)POLICY_LUT_WORDS, "one policy-table word per thread");
+    u32 plw = 0, olw = 0;
+    if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) plw = reinterpret_cast<const u32 *>(&g_policy_lut)[threadIdx.x];
+    if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olw = (&g_obs_lut.sel[0][0])[threadIdx.x];
     V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
     V64 q = load_stream(&reinterpret_cast<const V64 *>(pQ + ib)[g]);
     V16 act;
@@ -615,8 +624,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     if (!SAMPLE) act = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g]);
     if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
     fill_line_lut_nosync<BLOCK>(lut);
-    if (SAMPLE) fill_policy_lut<BLOCK>(plut);
-    if (OBS) fill_obs_lut<BLOCK>(olut);
+    if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) reinterpret_cast<u32 *>(plut)[threadIdx.x] = plw;
+    if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olut[threadIdx.x] = olw;
     ObsTiles T;
     if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
     __syncthreads();
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(const u64 *pP, cons
     constexpr u32 TILE_BOARDS = QTTT_BLOCK * 2;
     __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(TILE_BOARDS)];
     __shared__ __attribute__((aligned(16))) u32 olut[OBS_LUT_BYTES / 4];
-    fill_obs_lut<QTTT_BLOCK>(olut);
+    const u32 olw = threadIdx.x < OBS_LUT_BYTES / 4 ? (&g_obs_lut.sel[0][0])[threadIdx.x] : 0u;   // see step_kernel
     const int64_t base = (int64_t)blockIdx.x * TILE_BOARDS;
     const u32 valid = (u32)min((int64_t)TILE_BOARDS, n - base);
     const ObsTiles T = obs_tiles<TILE_BOARDS>(otile, obs, base);
@@ -1025,6 +1034,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(const u64 *pP, cons
         p.v[0] = pP[base + b0];
         q.v[0] = pQ[base + b0];
     }
+    if (threadIdx.x < OBS_LUT_BYTES / 4) olut[threadIdx.x] = olw;
     __syncthreads();
     if (b0 < valid) obs_board((u32)p.v[0], (u32)(p.v[0] >> 32), (u32)q.v[0], T, b0, olut);
     if (b0 + 1u < valid) obs_board((u32)p.v[1], (u32)(p.v[1] >> 32), (u32)q.v[1], T, b0 + 1u, olut);
@@ -1196,11 +1206,12 @@ __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     const u64 *pP, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint16_t *actions,
     int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    const u64 Pw = i < n ? load_stream(&pP[i]) : 0ull;      // requested before the table: the latencies overlap
     fill_policy_lut<QTTT_BLOCK>(plut);
     __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u32 P1 = (u32)(pP[i] >> 32);
+    const u32 P1 = (u32)(Pw >> 32);
     const u32 cl = (auto_reset && (P1 >> 31)) ? 0u : (P1 >> P1_CL_SHIFT) & 0x1FFu;
     const u32 empty = ~cl & 0x1FFu;
     const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
@@ -1227,11 +1238,11 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;   // before the table fill
     fill_pyhash_lut<QTTT_BLOCK>(htbl);
     __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
     const Lite s = lite_unpack(P);
     int w, t;
     fast_update_winner(s, w, t);
@@ -1249,12 +1260,12 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
     int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
+    const u32 a = i < n ? (u32)action36[i] : 0u;
     fill_pyhash_lut<QTTT_BLOCK>(htbl);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 P = pP[i], Q = pQ[i];
-    const u32 a = action36[i];
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
     const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
     u64 kidP[2], kidQ[2];
@@ -1297,11 +1308,11 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     int8_t *result, uint8_t *plies, u64 *fP, u64 *fQ, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
     fill_policy_lut<QTTT_BLOCK>(plut);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 P = pP[i], Q = pQ[i];
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
     const u32 id = fold_id(board_offset + (u64)i);
     u32 played = 0;
