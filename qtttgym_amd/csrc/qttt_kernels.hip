@@ -429,6 +429,42 @@ __host__ __device__ constexpr u32 obs_lds_bytes(u32 boards) {
            3u * obs_tile_bytes(boards, 1);
 }
 
+// Wave-private copy-out: the 64 * BPL boards of one wave occupy one contiguous, dword-aligned span
+// of every tile (as long as the tile itself starts on a dword, phase 0), so the wave that wrote the
+// rows can stream them out itself right away — LDS operations of one wave execute in order, no
+// workgroup barrier is needed, and its stores overlap the other waves' compute.
+__device__ inline void wave_copy_out(uint8_t *gdst, const uint8_t *tile16, u32 begin, u32 end) {
+    const u32 lane = threadIdx.x & 63u;
+    u32 *gd = reinterpret_cast<u32 *>(gdst);
+    const u32 *sd = reinterpret_cast<const u32 *>(tile16);
+    const u32 d0 = begin >> 2, d1 = end >> 2;                       // begin is a multiple of 4
+    for (u32 k = d0 + lane; k < d1; k += 64u) __builtin_nontemporal_store(sd[k], &gd[k]);
+    const u32 k = (d1 << 2) + lane;                                  // the last board of the batch may end mid-dword
+    if (k < end) gdst[k] = tile16[k];
+}
+
+// true iff every tile of this workgroup starts on a dword in global memory (block-uniform)
+__device__ __forceinline__ bool obs_all_phase0(const ObsOut &o, int64_t first) {
+    return ((obs_phase(reinterpret_cast<const uint8_t *>(o.classical) + first * 9) | obs_phase(o.q_p1 + first * 10) |
+             obs_phase(o.q_p2 + first * 8) | obs_phase(o.q_p1_len + first) | obs_phase(o.q_p2_len + first) |
+             obs_phase(o.turn + first)) == 0u);
+}
+
+template <u32 BOARDS>
+__device__ inline void obs_wave_copy_out(uint8_t *lds, const ObsOut &o, int64_t first, u32 b0, u32 b1) {
+    wave_copy_out(reinterpret_cast<uint8_t *>(o.classical) + first * 9, lds, b0 * 9u, b1 * 9u);
+    lds += obs_tile_bytes(BOARDS, 9);
+    wave_copy_out(o.q_p1 + first * 10, lds, b0 * 10u, b1 * 10u);
+    lds += obs_tile_bytes(BOARDS, 10);
+    wave_copy_out(o.q_p2 + first * 8, lds, b0 * 8u, b1 * 8u);
+    lds += obs_tile_bytes(BOARDS, 8);
+    wave_copy_out(o.q_p1_len + first, lds, b0, b1);
+    lds += obs_tile_bytes(BOARDS, 1);
+    wave_copy_out(o.q_p2_len + first, lds, b0, b1);
+    lds += obs_tile_bytes(BOARDS, 1);
+    wave_copy_out(o.turn + first, lds, b0, b1);
+}
+
 template <u32 BOARDS>
 __device__ __forceinline__ ObsTiles obs_tiles(uint8_t *lds, const ObsOut &o, int64_t first) {
     ObsTiles t;
@@ -669,8 +705,16 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
         store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g], tm);
     }
     if (OBS) {
-        __syncthreads();
-        obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, ib, ng * BPL);
+        // a wave's boards [64w * BPL, 64(w+1) * BPL) start on a multiple of 4 bytes in every tile
+        if ((64u * BPL) % 4u == 0u && obs_all_phase0(obs, ib)) {
+            const u32 w0 = (threadIdx.x & ~63u) * BPL;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // rows written by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+            if (w0 < ng * BPL) obs_wave_copy_out<TILE_BOARDS>(otile, obs, ib, w0, min(w0 + 64u * BPL, ng * BPL));
+        } else {
+            __syncthreads();
+            obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, ib, ng * BPL);
+        }
     }
 #ifdef QTTT_DEBUG_STAMPS
     const u64 st2 = __builtin_amdgcn_s_memrealtime();
