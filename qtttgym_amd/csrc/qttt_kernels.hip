@@ -1082,8 +1082,15 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(const u64 *pP, cons
     __syncthreads();
     if (b0 < valid) obs_board((u32)p.v[0], (u32)(p.v[0] >> 32), (u32)q.v[0], T, b0, olut);
     if (b0 + 1u < valid) obs_board((u32)p.v[1], (u32)(p.v[1] >> 32), (u32)q.v[1], T, b0 + 1u, olut);
-    __syncthreads();
-    obs_copy_out<QTTT_BLOCK, TILE_BOARDS>(otile, obs, base, valid);
+    if (obs_all_phase0(obs, base)) {                      // every wave streams out the rows it wrote (see step_kernel)
+        const u32 w0 = (threadIdx.x & ~63u) * 2u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (w0 < valid) obs_wave_copy_out<TILE_BOARDS>(otile, obs, base, w0, min(w0 + 128u, valid));
+    } else {
+        __syncthreads();
+        obs_copy_out<QTTT_BLOCK, TILE_BOARDS>(otile, obs, base, valid);
+    }
 }
 
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(

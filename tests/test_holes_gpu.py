@@ -220,3 +220,28 @@ def test_fused_step_observe_with_explicit_bits_and_offset_views():
                                big["classical"].data_ptr(), odd[1:].data_ptr(), big["q_states_p1_len"].data_ptr(),
                                big["q_states_p2"].data_ptr(), big["q_states_p2_len"].data_ptr(),
                                big["turn"].data_ptr(), n, s) == -3
+
+
+def test_export_into_offset_views_equals_plain_export():
+    """qttt_export into a caller's views offset by one board (odd byte addresses for the 18-, 9- and
+    1-byte rows) gives the same rows as into fresh tensors and touches nothing in front of the view,
+    at a ragged size, mid-game and at the end of the game."""
+    from qtttgym_amd import VecEnv, _native
+    n = 1003
+    L = _native.lib()
+    env = VecEnv(n, seed=14)
+    s = torch.cuda.current_stream().cuda_stream
+    for t in range(9):
+        env.step_random()
+        want = env.export_boards()
+        big = {"moves": torch.zeros((n + 1, 9, 2), dtype=torch.uint8, device="cuda"),
+               "n_moves": torch.zeros(n + 1, dtype=torch.uint8, device="cuda"),
+               "board": torch.zeros((n + 1, 9), dtype=torch.int8, device="cuda"),
+               "qmask": torch.zeros((n + 1, 4), dtype=torch.int16, device="cuda"),
+               "n_q": torch.zeros(n + 1, dtype=torch.uint8, device="cuda")}
+        rc = L.qttt_export(env.state.data_ptr(), big["moves"][1:].data_ptr(), big["n_moves"][1:].data_ptr(),
+                           big["board"][1:].data_ptr(), big["qmask"][1:].data_ptr(), big["n_q"][1:].data_ptr(), n, s)
+        assert rc == 0
+        for k in want:
+            assert torch.equal(big[k][1:], want[k]), (t, k)
+            assert int(big[k][0].to(torch.int64).abs().sum()) == 0, k

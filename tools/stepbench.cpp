@@ -101,6 +101,8 @@ struct Lib {
     int (*sample)(const void *, uint64_t, uint32_t, int64_t, uint32_t, uint8_t *, int64_t, void *);
     int (*set_tuning)(int, int);
     int (*step_wpb)(void *, const uint8_t *, const uint8_t *, uint64_t, uint32_t, int64_t, uint32_t, float *, uint8_t *, int64_t, void *);
+    int (*step_obs)(void *, const uint8_t *, const uint8_t *, uint64_t, uint32_t, int64_t, uint32_t, float *, uint8_t *, int8_t *,
+                    uint8_t *, uint8_t *, uint8_t *, uint8_t *, uint8_t *, int64_t, void *);
     std::vector<float> us;
 };
 
@@ -122,6 +124,7 @@ int main(int argc, char **argv) {
         SYM(state_bytes, "qttt_state_bytes") SYM(reset, "qttt_reset") SYM(step, "qttt_step")
         SYM(step_many, "qttt_step_many") SYM(sample, "qttt_sample_actions") SYM(set_tuning, "qttt_set_tuning")
         *(void **)(&L.step_wpb) = dlsym(L.h, "qttt_step_wave_per_board");   // optional
+        *(void **)(&L.step_obs) = dlsym(L.h, "qttt_step_observe");          // optional (STEPBENCH_OBS=1 times it)
         libs.push_back(L);
     }
     void *state; uint8_t *actions, *term; float *reward;
@@ -130,6 +133,11 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&reward, n * 4));
     CK(hipMalloc(&term, n));
     hipStream_t s; CK(hipStreamCreate(&s));
+    // STEPBENCH_OBS=1: time qttt_step_observe (step + observation, one kernel) instead of qttt_step
+    const bool obs_mode = getenv("STEPBENCH_OBS") != nullptr;
+    int8_t *o_cl; uint8_t *o_p1, *o_l1, *o_p2, *o_l2, *o_tn;
+    CK(hipMalloc(&o_cl, n * 9)); CK(hipMalloc(&o_p1, n * 10)); CK(hipMalloc(&o_l1, n)); CK(hipMalloc(&o_p2, n * 8));
+    CK(hipMalloc(&o_l2, n)); CK(hipMalloc(&o_tn, n));
     Lib &L0 = libs[0];
     L0.set_tuning(L0.bpl, L0.pipe);
     L0.reset(state, n, s);
@@ -148,7 +156,14 @@ int main(int argc, char **argv) {
             L.reset(state, n, s);
             L.step_many(state, actions, nullptr, seed, 0, 0, 1, reward, term, 0, n, W, s);
             CK(hipEventRecord(e0, s));
-            int rc = L.step_many(state, actions + (size_t)W * 2 * n, nullptr, seed, W, 0, 1, reward, term, 0, n, K, s);
+            int rc = 0;
+            if (obs_mode && L.step_obs) {
+                for (int t = 0; t < K && !rc; ++t)
+                    rc = L.step_obs(state, actions + (size_t)(W + t) * 2 * n, nullptr, seed, W + t, 0, 1, reward, term, o_cl, o_p1,
+                                    o_l1, o_p2, o_l2, o_tn, n, s);
+            } else {
+                rc = L.step_many(state, actions + (size_t)W * 2 * n, nullptr, seed, W, 0, 1, reward, term, 0, n, K, s);
+            }
             CK(hipEventRecord(e1, s));
             CK(hipStreamSynchronize(s));
             if (rc) { fprintf(stderr, "step rc=%d\n", rc); return 1; }
