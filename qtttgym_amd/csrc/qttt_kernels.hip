@@ -109,35 +109,12 @@ __device__ __forceinline__ V load_stream(const V *p) {
     __builtin_memcpy(&v, &r, sizeof(V));
     return v;
 }
-#ifndef QTTT_STORE_POLICY
-#define QTTT_STORE_POLICY 0      // 0 = nt (product), 1 = sc1, 2 = plain, 3 = sc0 sc1 (experiments, tools/stepbench)
-#endif
 template <typename V>
 __device__ __forceinline__ void store_stream(V *p, const V &v) {
     typedef typename RawOf<sizeof(V)>::type R;
     R r;
     __builtin_memcpy(&r, &v, sizeof(V));
-#if QTTT_STORE_POLICY == 0
     __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
-#elif QTTT_STORE_POLICY == 2
-    *reinterpret_cast<R *>(p) = r;
-#else
-#if QTTT_STORE_POLICY == 1
-#define QTTT_ST_MOD " sc1"
-#else
-#define QTTT_ST_MOD " sc0 sc1"
-#endif
-    if constexpr (sizeof(V) == 32) {
-        const u32x4 *h = reinterpret_cast<const u32x4 *>(&r);
-        const u32x4 h0 = h[0], h1 = h[1];
-        asm volatile("global_store_dwordx4 %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(h0) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, off offset:16" QTTT_ST_MOD :: "v"(p), "v"(h1) : "memory");
-    } else if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(r) : "memory");
-    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(r) : "memory");
-    else if constexpr (sizeof(V) == 4) asm volatile("global_store_dword %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(r) : "memory");
-    else if constexpr (sizeof(V) == 2) { const u32 w = r; asm volatile("global_store_short %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(w) : "memory"); }
-    else { const u32 w = r; asm volatile("global_store_byte %0, %1, off" QTTT_ST_MOD :: "v"(p), "v"(w) : "memory"); }
-#endif
 }
 
 __device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
