@@ -110,7 +110,7 @@ def self_launch(args):
 
 
 # ---------------------------------------------------------------------------- roofline inputs
-def pmc_traffic_per_launch(boards, state_bytes):
+def pmc_traffic_per_launch(boards, state_bytes, suffix=""):
     """HBM bytes per step launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction in
     MI355X_MICROARCH.md §HBM).  Not measured in this run: `traffic_source` names the file.
@@ -118,7 +118,7 @@ def pmc_traffic_per_launch(boards, state_bytes):
     try:
         with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             d = json.load(f)
-        e = d.get("%d@%dB" % (boards, state_bytes)) or d.get(str(boards))
+        e = d.get("%d@%dB%s" % (boards, state_bytes, suffix))
         if e is None or int(e.get("state_bytes_per_board", 20)) != state_bytes:
             return None
         return float(e["hbm_bytes_per_launch"])
@@ -340,7 +340,8 @@ def run(args):
                       if args.mode in ("replay", "gym") else
                       "step_kernel<%d, %d, false, true, true, false>" % (blk, bpl) if args.mode == "random" else
                       "sample_actions_kernel + step_kernel<%d, %d, false, true, false, false>" % (blk, bpl))
-            traffic = None if args.mode != "replay" else pmc_traffic_per_launch(B, state_bytes)
+            traffic = (pmc_traffic_per_launch(B, state_bytes) if args.mode == "replay" else
+                       pmc_traffic_per_launch(B, state_bytes, "+gym") if gym else None)
             what = {"replay": "recorded actions replayed (env.step only in the timed region)",
                     "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel)",
                     "policy": "policy kernel + env.step per step",
