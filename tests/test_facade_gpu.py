@@ -214,3 +214,40 @@ def test_board_call_is_one_launch_without_copies(bits):
     s.synchronize()
     assert rec_out.numpy()[41] == 1 and rec_out.numpy()[18] == 1
     assert L.qttt_board_op(None, rec_out.data_ptr(), 1, None) == -1 and L.qttt_board_op(None, None, 0, None) == 0
+
+
+def test_board_op_batches_records(golden):
+    """qttt_board_op takes n records per launch: a whole golden step for 300 boards at once, every
+    board imported from the reference's attributes before the move and compared after it."""
+    import torch
+    from qtttgym_amd import _native
+    L = _native.lib()
+    g = golden
+    E = 300
+    rin = torch.zeros((E, 64), dtype=torch.uint8).pin_memory()
+    rout = torch.zeros((E, 64), dtype=torch.uint8).pin_memory()
+    s = torch.cuda.current_stream()
+    T = g["bits"].shape[1]
+    for t in range(1, T):
+        a = rin.numpy()
+        a[:, 0:18] = g["moves"][:E, t - 1].reshape(E, 18)
+        a[:, 18] = g["n_moves"][:E, t - 1]
+        a[:, 19:28] = g["board"][:E, t - 1].view(np.uint8)
+        a[:, 28] = g["n_q"][:E, t - 1]
+        a[:, 29] = _native.OP_MAKE_MOVE
+        a[:, 30:38] = g["qmask"][:E, t - 1].astype("<u2").view(np.uint8).reshape(E, 8)
+        a[:, 38:40] = g["actions"][:E, t]
+        a[:, 40] = g["bits"][:E, t]
+        assert L.qttt_board_op(rin.data_ptr(), rout.data_ptr(), E, s.cuda_stream) == 0
+        s.synchronize()
+        o = rout.numpy()
+        nm = g["n_moves"][:E, t]
+        assert np.array_equal(o[:, 18], nm), t
+        assert np.array_equal(o[:, 19:28].view(np.int8), g["board"][:E, t]), t
+        assert np.array_equal(o[:, 0:18].reshape(E, 9, 2), g["moves"][:E, t]), t
+        assert np.array_equal(o[:, 28], g["n_q"][:E, t]), t
+        assert np.array_equal(o[:, 30:38].copy().view("<u2").reshape(E, 4), g["qmask"][:E, t]), t
+        assert np.array_equal(o[:, 41], (g["n_moves"][:E, t] == g["n_moves"][:E, t - 1]).astype(np.uint8)), t   # rejected <=> nothing appended
+        assert np.array_equal(o[:, 44:48].copy().view("<u4")[:, 0], g["reward"][:E, t].astype(np.float32).view(np.uint32)), t
+        assert np.array_equal(o[:, 48], g["terminated"][:E, t]), t
+        assert np.array_equal(o[:, 49].view(np.int8), g["p1_round"][:E, t]) and np.array_equal(o[:, 50].view(np.int8), g["p2_round"][:E, t]), t

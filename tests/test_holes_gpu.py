@@ -245,3 +245,29 @@ def test_export_into_offset_views_equals_plain_export():
         for k in want:
             assert torch.equal(big[k][1:], want[k]), (t, k)
             assert int(big[k][0].to(torch.int64).abs().sum()) == 0, k
+
+
+def test_ragged_batch_on_the_1024_thread_workgroup_path():
+    """Batches of >= 1 M boards run with 1024-thread workgroups; a size that leaves the last workgroup
+    with three lane-groups and one odd board (its own 1-board-per-lane launch) must still be the
+    oracle's function — step alone, and step + observation against the two-kernel path."""
+    from qtttgym_amd import VecEnv
+    n, seed, off = (1 << 20) + 7, 61, 1234567
+    env = VecEnv(n, seed=seed, auto_reset=True, board_offset=off)
+    fused = VecEnv(n, seed=seed, auto_reset=True, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    for t in range(10):
+        a = env.sample_actions()
+        a_or = ob.sample_actions(seed, t, off, True)
+        assert np.array_equal(_np(a), a_or), t
+        r, tm = env.step_raw(a)
+        r_or, t_or = ob.step(a_or, None, seed, t, off, True)
+        assert np.array_equal(_np(r).view(np.uint32), r_or.view(np.uint32)), t
+        assert np.array_equal(_np(tm).astype(np.uint8), t_or), t
+        obs_f, r_f, t_f = fused.step_observe_raw(a)
+        assert torch.equal(r_f.view(torch.int32), r.view(torch.int32)) and torch.equal(t_f, tm), t
+        assert torch.equal(fused.state, env.state), t
+        obs_s = env.observ()
+        for k in obs_s:
+            assert torch.equal(obs_f[k], obs_s[k]), (t, k)
+    _assert_same_as_oracle(env, ob)
