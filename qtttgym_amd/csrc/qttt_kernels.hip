@@ -1082,26 +1082,43 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
     p2_round[i] = (int8_t)p2;
 }
 
+// Board.moves / .board / .qstructs (board.py:4-6) as arrays, straight from the packed words: the
+// move of round t is (c, c ^ x_t) for its holder c (found through the same inverse map as in
+// fast_py_hash), the board is the nibbles of the classical squares, the qstructs are the cached
+// slots.
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
     const u64 *pP, const u64 *pQ, uint8_t *moves, uint8_t *n_moves,
     int8_t *board, uint16_t *qmask, uint8_t *n_q, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
     if (i >= n) return;
-    Cold s;
-    cold_unpack(pP[i], pQ[i], s);
+    const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
+    const u32 P1 = (u32)(P >> 32), Q0 = (u32)Q;
+    const Lite s = lite_unpack(P);
+    u64 H = 0;                                                // nibble (code - 7) = holder square + 1
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) {
+        const u32 c = (u32)(s.P >> (4u * v + 2u)) & 0xFu;
+        H |= (u64)(v + 1u) << ((4u * c + 36u) & 63u);
+        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)(15u - c) : (int8_t)-1;
+    }
+#pragma unroll
     for (u32 t = 0; t < 9; ++t) {
+        const u32 h = (u32)(H >> (4u * (8u - t))) & 0xFu;
+        const u32 c = h ? h - 1u : 0u;
+        const u32 x = (t >= s.n_real) ? 0u : cold_move_x(Q0, P1, s.n_real, t);     // autofill = (idx, idx)
+        const u32 o = c ^ x;
         const bool used = t < s.n;
-        const u32 m = s.mv(t);
-        moves[i * 18 + t * 2] = used ? (uint8_t)(m & 0xFu) : (uint8_t)255;
-        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)(m >> 4) : (uint8_t)255;
+        moves[i * 18 + t * 2] = used ? (uint8_t)min(c, o) : (uint8_t)255;
+        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)max(c, o) : (uint8_t)255;
     }
     n_moves[i] = (uint8_t)s.n;
-    for (u32 v = 0; v < 9; ++v)
-        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)s.sqv(v) : (int8_t)-1;
+    const u64 comps = (Q >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
     u32 nq = 0;
+#pragma unroll
     for (u32 k = 0; k < 4; ++k) {
-        qmask[i * 4 + k] = (uint16_t)s.comp(k);
-        nq += s.comp(k) != 0u;
+        const u32 m = (u32)(comps >> (9u * k)) & 0x1FFu;
+        qmask[i * 4 + k] = (uint16_t)m;
+        nq += m != 0u;
     }
     n_q[i] = (uint8_t)nq;
 }
