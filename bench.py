@@ -318,11 +318,25 @@ def run(args):
     ev_med, wall_med = all_max(median(ev_s)), all_max(median(wall_s))
     ev_min = all_max(min(ev_s))
 
+    gather = None
     if world > 1:
         # episode counters: the only exchange in the design, once per run, off the timed path
         cnt = torch.stack([term_count, win_count]).to(coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         term_count, win_count = cnt[0], cnt[1]
+        # and the optional one: a gather of per-board returns (4 B per board) to rank 0, timed on its
+        # own (RCCL over xGMI on a multi-GPU node; never part of a step)
+        from qtttgym_amd.dist import gather_returns
+        ret = env._reward.clone().to(coll_dev)
+        gather_returns(ret, dst=0)                           # untimed: connection set-up of the gather
+        torch.cuda.synchronize(dev)
+        barrier()
+        tg0 = time.perf_counter()
+        gathered = gather_returns(ret, dst=0)
+        torch.cuda.synchronize(dev)
+        tg = all_max(time.perf_counter() - tg0)
+        gather = {"ms": tg * 1e3, "bytes_per_rank": 4 * B, "backend": backend,
+                  "boards_gathered": None if gathered is None else int(gathered.numel())}
 
     rc = 0
     if rank == 0:
@@ -353,7 +367,7 @@ def run(args):
                 "data": "synthetic",
                 "clock": "HIP events on the launch stream around the K launches; median of %d regions "
                          "(max over ranks); value, ms_per_step and roofline all use it" % R,
-                "regions": R, "host_wall_ms_per_step": wall_med * 1e3 / K,
+                "regions": R, "host_wall_ms_per_step": wall_med * 1e3 / K, "returns_gather": gather,
                 "best_region_ms_per_step": ev_min * 1e3 / K,
                 "config": {"workload": "%d boards per GPU, uniform-legal random policy, auto-reset, %s" % (B, what),
                            "boards_per_gpu": B, "boards_total": B * world, "state_bytes_per_board": state_bytes,

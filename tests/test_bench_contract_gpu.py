@@ -74,6 +74,8 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert d["config"]["parallelism"] == "shard2"
     assert d["config"]["replay_matches_recording"] is True
     assert abs(d["value"] - 2 * 32768 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    g = d["returns_gather"]                                         # the optional exchange, off the step path
+    assert g["boards_gathered"] == 65536 and g["bytes_per_rank"] == 4 * 32768 and g["ms"] > 0
 
 
 def test_bench_refuses_more_ranks_than_gpus_on_rccl():
