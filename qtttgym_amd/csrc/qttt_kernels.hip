@@ -943,16 +943,32 @@ __device__ __forceinline__ void fast_check_win(const Lite &s, int &p1, int &p2) 
     p2 = lut[O & ge[1]] ? 5 : (lut[O] ? 7 : -1);
 }
 
-// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal
-__device__ __forceinline__ void fast_update_winner(const Lite &s, int &winner, int &terminal) {
-    int p1, p2;
-    fast_check_win(s, p1, p2);
-    winner = -1;
-    terminal = 0;
-    if (p1 > 0 && p2 > 0) { winner = p1 < p2; terminal = 1; }
-    else if (p2 < 0 && p1 > 0) { winner = 1; terminal = 1; }
-    else if (p1 < 0 && p2 > 0) { winner = 0; terminal = 1; }
-    terminal = (s.n == 9u) || terminal;
+// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal = a line or
+// nine moves.  Through the workgroup's LDS line table (the step kernel's: a dword per mask, read at
+// mask * 4): who holds a line takes two gathers; the rounds matter only when both players do
+// (p1 in {4,6,8}, p2 in {5,7}: p1 < p2 <=> p1 == 4, or p1 == 6 and p2 == 7), a branch most waves skip.
+__device__ __forceinline__ void lite_update_winner(const Lite &s, const uint8_t *lut, int &winner, int &terminal) {
+    const u32 W = (u32)(s.P >> 2);
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+    const u32 par = W & 0x11111111u;
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((c8 & 1u) << 8);
+    const u32 X = s.cl & even, O = s.cl & ~even;
+    const u32 *l32 = reinterpret_cast<const u32 *>(lut);
+    const bool hx = l32[X] != 0u, ho = l32[O] != 0u;
+    winner = hx ? 1 : (ho ? 0 : -1);
+    if (hx && ho) {
+        u32 ge[3];
+#pragma unroll
+        for (u32 k = 0; k < 3; ++k) {                                // code >= 9, 10, 11  <=>  round <= 6, 5, 4
+            const u32 T = 9u + k;
+            const u32 y = ((W & 0x77777777u) + 0x11111111u * (16u - T)) & W & 0x88888888u;
+            ge[k] = ((__builtin_amdgcn_udot8(y, 0x00008421u, 0u, false) |
+                      (__builtin_amdgcn_udot8(y, 0x84210000u, 0u, false) << 4)) >> 3) | ((c8 >= T ? 1u : 0u) << 8);
+        }
+        winner = (l32[X & ge[2]] != 0u || (l32[X & ge[0]] != 0u && l32[O & ge[1]] == 0u)) ? 1 : 0;
+    }
+    terminal = (s.n == 9u || hx || ho) ? 1 : 0;
 }
 
 // GameState.actions (mcts.py:20-27) in ind2move order (mcts.py:339-343): the pairs (i, j > i) of
@@ -967,6 +983,29 @@ __device__ __forceinline__ u64 fast_legal_mask(u32 cl) {
         off += 8u - i;
     }
     return m;
+}
+
+// the same as a table over the nine classical bits, for kernels that have an LDS copy of it
+__host__ __device__ constexpr u64 legal_mask_of(u32 cl) {
+    const u32 E = ~cl & 0x1FFu;
+    u64 m = 0;
+    u32 off = 0;
+    for (u32 i = 0; i < 8; ++i) {
+        m |= (u64)((E >> i & 1u) ? (E >> (i + 1u)) : 0u) << off;
+        off += 8u - i;
+    }
+    return m;
+}
+struct LegalLut {
+    u64 m[512];
+    constexpr LegalLut() : m() {
+        for (u32 cl = 0; cl < 512; ++cl) m[cl] = legal_mask_of(cl);
+    }
+};
+__device__ const LegalLut g_legal_lut = LegalLut();
+template <int BLOCK>
+__device__ inline void fill_legal_lut(u64 *dst) {
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) dst[w] = g_legal_lut.m[w];
 }
 
 // GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
@@ -985,7 +1024,7 @@ __host__ __device__ constexpr u64 pyh_fin(u64 acc, u64 len) {
 }
 struct PyHashLut {
     u64 board[10];          // [v + 1] for Board.board value v = -1..8
-    u64 move[9][9][9];      // [lo][hi][round]
+    u64 move[9][9][9];      // [a][b][round] for the move on squares {a, b}, either order
     constexpr PyHashLut() : board(), move() {
         board[0] = (u64)(long long)-2 * PYH_P2;
         for (u64 v = 0; v < 9; ++v) board[v + 1] = v * PYH_P2;
@@ -993,8 +1032,8 @@ struct PyHashLut {
             for (u64 b = 0; b < 9; ++b)
                 for (u64 t = 0; t < 9; ++t) {
                     u64 in = PYH_P5;
-                    in = pyh_step(in, a * PYH_P2);
-                    in = pyh_step(in, b * PYH_P2);
+                    in = pyh_step(in, (a < b ? a : b) * PYH_P2);    // Board.moves holds (lo, hi, round)
+                    in = pyh_step(in, (a < b ? b : a) * PYH_P2);
                     in = pyh_step(in, t * PYH_P2);
                     move[a][b][t] = pyh_fin(in, 3) * PYH_P2;
                 }
@@ -1013,20 +1052,35 @@ __device__ inline void fill_pyhash_lut(u64 *dst) {
 
 __device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0, const u64 *tbl) {
     u64 acc = PYH_P5;
-    // holders of every round: nibble (code - 7) of H = square + 1 (code 0 = no move lands in nibble 9)
-    u64 H = 0;
+    const u32 W = (u32)(s.P >> 2);                                  // codes of squares 0..7
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
 #pragma unroll
     for (u32 v = 0; v < 9; ++v) {
-        const u32 c = (u32)(s.P >> (4u * v + 2u)) & 0xFu;
-        acc = pyh_step(acc, tbl[(s.cl >> v & 1u) ? 16u - c : 0u]);   // board[value + 1], value = 15 - c
-        H |= (u64)(v + 1u) << ((4u * c + 36u) & 63u);
+        const u32 c = v < 8u ? (W >> (4u * v)) & 0xFu : c8;
+        acc = pyh_step(acc, tbl[(s.cl >> v & 1u) ? 16u - c : 0u]);  // board[value + 1], value = 15 - c
     }
-    for (u32 t = 0; t < s.n; ++t) {
-        const u32 h = (u32)(H >> (4u * (8u - t))) & 0xFu;
-        const u32 c = h ? h - 1u : 0u;                              // the square that holds round t
-        const u32 x = (t >= s.n_real) ? 0u : cold_move_x(Q0, P1_stored, s.n_real, t);   // autofill = (idx, idx)
-        const u32 o = min(c ^ x, 8u);                               // (only a corrupted import could exceed 8)
-        acc = pyh_step(acc, tbl[10u + (min(c, o) * 9u + max(c, o)) * 9u + t]);   // move[lo][hi][t]
+    // moves in round order: round t is held by the one square whose code is 15 - t (zero nibble of
+    // W ^ 0x1111_1111 * code; the lowest flag of the borrow trick is always a true zero; no flag =
+    // square 8), and is (c, c ^ x_t).  x nibbles: round 0 in bits 0..3 of Qr, round t >= 1 at 32 - 4t.
+    const u32 last_x = (P1_stored >> P1_LX_SHIFT) & 0xFu;
+    const u32 Qr = rotr32(Q0, 30u) ^ (s.n_real == 9u ? last_x : 0u);  // round 8's x was XORed onto round 0's
+    const u32 n8 = min(s.n, 8u);
+    u32 kk = 0xFFFFFFFFu, sh = 0u;
+    for (u32 t = 0; t < n8; ++t) {                                  // (an autofill move is always round 8)
+        const u32 z = W ^ kk;
+        const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
+        const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
+        const u32 o = min(c ^ ((Qr >> sh) & 0xFu), 8u);             // (only a corrupted import could exceed 8)
+        acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + t]);
+        kk -= 0x11111111u;
+        sh = (sh - 4u) & 31u;
+    }
+    if (s.n == 9u) {
+        const u32 z = W ^ 0x77777777u;
+        const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
+        const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
+        const u32 o = min(c ^ (s.n_real == 9u ? last_x : 0u), 8u);  // autofill = (idx, idx)
+        acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + 8u]);
     }
     return (int64_t)pyh_fin(acc, 9u + s.n);
 }
@@ -1283,17 +1337,20 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    __shared__ u64 ltbl[512];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;   // before the table fill
     fill_pyhash_lut<QTTT_BLOCK>(htbl);
-    __syncthreads();
+    fill_legal_lut<QTTT_BLOCK>(ltbl);
+    fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     const Lite s = lite_unpack(P);
     int w, t;
-    fast_update_winner(s, w, t);
+    lite_update_winner(s, lut, w, t);
     winner[i] = (int8_t)w;
     terminal[i] = (uint8_t)t;
-    legal[i] = fast_legal_mask(s.cl);
+    legal[i] = ltbl[s.cl];
     key[i] = fast_py_hash(s, (u32)(P >> 32), (u32)Q, htbl);
 }
 
@@ -1334,7 +1391,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
         int64_t k = 0;
         if (c < kids) {
             const Lite s = lite_unpack(kidP[c]);
-            fast_update_winner(s, w, t);
+            lite_update_winner(s, lut, w, t);
             lm = fast_legal_mask(s.cl);
             k = fast_py_hash(s, (u32)(kidP[c] >> 32), (u32)kidQ[c], htbl);
         }
@@ -1372,7 +1429,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     }
     const u64 oP = (u64)P0 | ((u64)P1 << 32), oQ = (u64)Q0 | ((u64)Q1 << 32);
     int w, t;
-    fast_update_winner(lite_unpack(oP), w, t);
+    lite_update_winner(lite_unpack(oP), lut, w, t);
     result[i] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));       // MCTS._reward, mcts.py:200-209
     plies[i] = (uint8_t)played;
     if (fP) { fP[i] = oP; fQ[i] = oQ; }
