@@ -61,37 +61,46 @@ class _Staging:
         self.t_out = torch.zeros(nb, dtype=torch.uint8).pin_memory()
         self.a_in = self.t_in.numpy()          # plain memory views of the pinned buffers
         self.a_out = self.t_out.numpy()
+        self.m_in = memoryview(self.a_in)
+        self.p_in, self.p_out = self.t_in.data_ptr(), self.t_out.data_ptr()
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def run(self, board, op, lo=0, hi=0, bit=0, drop_last_move=False):
         """Ships board's attributes + the move, runs qttt_board_op, returns the out record."""
-        a = self.a_in
         moves = board.moves[:-1] if drop_last_move else board.moves
-        n = min(len(moves), 9)
-        a[0:18] = 255
-        for i in range(n):
-            m = moves[i]
-            a[2 * i], a[2 * i + 1] = m[0] & 255, m[1] & 255
-        a[18] = n
-        for v in range(9):
-            a[19 + v] = board.board[v] & 255
-        nq = min(len(board.qstructs), 4)
-        a[28] = nq
-        a[29] = op
-        for k in range(4):
+        if len(moves) > 9:
+            moves = moves[:9]
+        n = len(moves)
+        qs = board.qstructs
+        nq = min(len(qs), 4)
+        masks = [0, 0, 0, 0]
+        for k in range(nq):
             mask = 0
-            if k < nq:
-                for x in board.qstructs[k]:
-                    mask |= 1 << int(x)
-            a[30 + 2 * k], a[31 + 2 * k] = mask & 255, mask >> 8
-        a[38], a[39], a[40] = lo, hi, bit
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device)
-            _native.check(self.lib.qttt_board_op(self.t_in.data_ptr(), self.t_out.data_ptr(), 1,
-                                                 stream.cuda_stream), "qttt_board_op")
-            stream.synchronize()
+            for x in qs[k]:
+                mask |= 1 << int(x)
+            masks[k] = mask & 0xFFFF
+        # the record is built as one bytes object and lands in the pinned buffer with one copy
+        self.m_in[0:41] = (bytes([v & 255 for m in moves for v in (m[0], m[1])]) + _PAD18[2 * n:] + bytes([n])
+                           + bytes([x & 255 for x in board.board[:9]])
+                           + bytes([nq, op, masks[0] & 255, masks[0] >> 8, masks[1] & 255, masks[1] >> 8,
+                                    masks[2] & 255, masks[2] >> 8, masks[3] & 255, masks[3] >> 8,
+                                    lo & 255, hi & 255, bit & 255]))
+        if torch.cuda.current_device() == self.device.index:
+            self._launch()
+        else:
+            with torch.cuda.device(self.device):
+                self._launch()
         return self.a_out
 
+    def _launch(self):
+        stream = torch.cuda.current_stream(self.device)
+        _native.check(self.lib.qttt_board_op(self.p_in, self.p_out, 1, stream.cuda_stream), "qttt_board_op")
+        stream.synchronize()
+
+
+_PAD18 = b"\xff" * 18
+_I8 = tuple(x - 256 if x > 127 else x for x in range(256))                           # u8 -> i8
+_SQUARES = tuple(tuple(v for v in range(9) if m >> v & 1) for m in range(512))       # mask -> squares
 
 _staging = None
 
@@ -114,14 +123,14 @@ class Board:
     # ------------------------------------------------------------------ device round trip
     def _adopt(self, o):
         """Takes the attributes back from an out record."""
-        n = int(o[18])
-        self.moves = [(int(o[2 * i]), int(o[2 * i + 1]), i) for i in range(n)]
-        self.board[:] = [int(x) - 256 if x > 127 else int(x) for x in o[19:28]]   # in place: env.py:71,82 aliasing
-        self.qstructs = [set(s for s in range(9) if (int(o[30 + 2 * k]) | int(o[31 + 2 * k]) << 8) >> s & 1)
-                         for k in range(int(o[28]))]
+        r = o.tobytes()                                    # one copy out of the pinned record
+        n = min(r[18], 9)
+        self.moves = list(zip(r[0:2 * n:2], r[1:2 * n:2], range(n)))
+        self.board[:] = [_I8[x] for x in r[19:28]]         # in place: env.py:71,82 aliasing
+        self.qstructs = [set(_SQUARES[(r[30 + 2 * k] | r[31 + 2 * k] << 8) & 511]) for k in range(min(r[28], 4))]
         # the out record carries check_win of the new state (a function of .board alone,
         # board.py:71-115): remembered, keyed by the board it belongs to
-        self._win = (tuple(self.board), self._i8(o[49]), self._i8(o[50]))
+        self._win = (tuple(self.board), _I8[r[49]], _I8[r[50]])
 
     @staticmethod
     def _i8(x):

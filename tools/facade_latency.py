@@ -47,7 +47,7 @@ def main():
     t_mm = (time.perf_counter() - t0) / n
     print(json.dumps({"row": "facade_latency_N1", "Env.step_us": t_env * 1e6, "Board.make_move_us": t_mm * 1e6,
                       "Board.check_win_us": t_cw * 1e6, "reference_Env.step_us": 12.0,
-                      "note": "Env.step = make_move + check_win = two qttt_board_op launches + two stream synchronisations"}))
+                      "note": "Env.step = one qttt_board_op launch + one stream synchronise (check_win comes back in the same record); the loop also pays the random legal move and Env.reset of each episode"}))
 
 
 if __name__ == "__main__":
