@@ -213,23 +213,28 @@ def run(args):
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # QTTT_DIST_FORCE=1: build the process group and run every collective of the N > 1 path with one
+    # rank too (a one-GPU box can then exercise the RCCL branch; tests/test_bench_contract_gpu.py)
+    use_dist = world > 1 or os.environ.get("QTTT_DIST_FORCE") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.barrier(device_ids=[dev_index])
             else:
                 dist.barrier()
 
     def all_max(x):
-        if world == 1:
+        if not use_dist:
             return float(x)
         t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,7 +242,7 @@ def run(args):
 
     # how many ranks the process group really has (RCCL's own count, not the environment's)
     ranks_seen = 1
-    if world > 1:
+    if use_dist:
         ones = torch.ones((), dtype=torch.int64, device=coll_dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(ones)
@@ -319,7 +324,7 @@ def run(args):
     ev_min = all_max(min(ev_s))
 
     gather = None
-    if world > 1:
+    if use_dist:
         # episode counters: the only exchange in the design, once per run, off the timed path
         cnt = torch.stack([term_count, win_count]).to(coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -372,7 +377,7 @@ def run(args):
                 "config": {"workload": "%d boards per GPU, uniform-legal random policy, auto-reset, %s" % (B, what),
                            "boards_per_gpu": B, "boards_total": B * world, "state_bytes_per_board": state_bytes,
                            "parallelism": "shard%d" % world, "mode": args.mode,
-                           "dist_backend": backend if world > 1 else None,
+                           "dist_backend": backend if use_dist else None,
                            "self_launched": bool(os.environ.get("QTTT_BENCH_SELF_LAUNCHED")),
                            "board_offset_last_rank": (world - 1) * B,
                            "replay_matches_recording": replay_ok,
@@ -389,8 +394,8 @@ def run(args):
                 t_cpu = min(T, 256)
                 out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed, args.cpu_budget)
             print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        barrier()
         dist.destroy_process_group()
     if not replay_ok:
         raise SystemExit("replay diverged from the recording")

@@ -78,6 +78,20 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert g["boards_gathered"] == 65536 and g["bytes_per_rank"] == 4 * 32768 and g["ms"] > 0
 
 
+def test_bench_rccl_branch_with_one_rank():
+    """The N > 1 code path on the real backend: process group on RCCL ("nccl"), device barrier,
+    all_reduce of the clock / the rank count / the episode counters, the returns gather — with the
+    one rank a one-GPU box can give it (two ranks on one GPU are refused by RCCL itself)."""
+    d = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                  env={"QTTT_DIST_FORCE": "1", "QTTT_DIST_BACKEND": "nccl"})
+    assert d["n_gpus"] == 1 == d["ranks_seen"] and d["config"]["dist_backend"] == "nccl"
+    assert d["returns_gather"]["backend"] == "nccl" and d["returns_gather"]["boards_gathered"] == 65536
+    assert d["config"]["replay_matches_recording"] is True
+    e = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    assert e["config"]["dist_backend"] is None and e["returns_gather"] is None
+    assert e["config"]["episodes_finished"] == d["config"]["episodes_finished"]
+
+
 def test_bench_refuses_more_ranks_than_gpus_on_rccl():
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QTTT_DIST_BACKEND"):
