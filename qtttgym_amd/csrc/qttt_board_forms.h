@@ -1,0 +1,321 @@
+// qttt_board_forms.h — unpacked views of the state for everything that is not the step: the generic
+// `Cold` form (import / export / board_op / encode), the `Lite` form of the MCTS-side kernels, win
+// check, winner, legal-action mask and the CPython tuple hash.
+#ifndef QTTT_BOARD_FORMS_H
+#define QTTT_BOARD_FORMS_H
+#include "qttt_state.h"
+
+namespace {
+
+// ====================================================================== cold paths
+// Friendly unpacked form for the kernels that are not on the hot path.  Everything is kept in
+// packed words with shift accessors — no per-thread arrays: runtime-indexed arrays would live in
+// scratch memory, and the scratch-backed version of these kernels returned an occasional wrong
+// element under 512-thread workgroups on this part (round 1).
+// tests/test_abi_and_host.py asserts that no kernel of this file uses scratch.
+struct Cold {
+    u32 n;          // n_moves, autofill move included
+    u32 cl;         // classical mask, autofilled square included
+    u32 done;
+    u64 mvq;        // moves of rounds 0..7: byte t = lo | hi<<4
+    u32 mv8;        // move of round 8
+    u64 sq;         // 9 nibbles, true values (0xF = root / isolated / empty)
+    u64 comps;      // 4 x 9-bit masks, list order
+    __device__ u32 mv(u32 t) const { return t >= 8u ? mv8 : (u32)(mvq >> (t * 8u)) & 0xFFu; }
+    __device__ void set_mv(u32 t, u32 m) {
+        if (t >= 8u) mv8 = m & 0xFFu;
+        else mvq = (mvq & ~(0xFFull << (t * 8u))) | ((u64)(m & 0xFFu) << (t * 8u));
+    }
+    __device__ u32 sqv(u32 v) const { return (u32)(sq >> (v * 4u)) & 0xFu; }
+    __device__ void set_sq(u32 v, u32 x) { sq = (sq & ~(0xFull << (v * 4u))) | ((u64)(x & 0xFu) << (v * 4u)); }
+    __device__ u32 comp(u32 k) const { return (u32)(comps >> (9u * k)) & 0x1FFu; }
+};
+
+// x = lo ^ hi of the move of round e (e < n real moves), see the layout notes at the top
+__device__ __forceinline__ u32 cold_move_x(u32 Q0, u32 P1, u32 n_real, u32 e) {
+    const u32 last_x = (P1 >> P1_LX_SHIFT) & 0xFu;
+    if (e >= 8u) return last_x;
+    u32 x = (rotr32(Q0, 4u * (7u - e)) >> 2) & 0xFu;
+    if (e == 0u && n_real == 9u) x ^= last_x;                   // round 8's x was XORed onto round 0's nibble
+    return x;
+}
+
+__device__ __forceinline__ void cold_unpack(u64 P, u64 Q, Cold &s, bool autofill = true) {
+    const u32 P1 = (u32)(P >> 32), Q0 = (u32)Q;
+    s.n = (P1 >> P1_N_SHIFT) & 0xFu;
+    s.cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    s.done = P1 >> 31;
+    s.sq = ((P >> 2) & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;         // stored complemented
+    s.comps = (Q >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
+    // Board.moves from the holders: the square c with sq[c] = e is one end of the move of round e
+    // (child end if un-collapsed, landing square if collapsed), the other end is c ^ x_e
+    s.mvq = 0;
+    s.mv8 = 0;
+    const u32 n_real = s.n;
+    for (u32 c = 0; c < 9; ++c) {
+        const u32 e = s.sqv(c);
+        if (e >= n_real) continue;                               // 0xF = root / isolated / empty
+        const u32 o = c ^ cold_move_x(Q0, P1, n_real, e);
+        s.set_mv(e, min(c, o) | (max(c, o) << 4));
+    }
+    // materialise the implicit autofill (board.py:22-25): exactly 8 classical squares
+    if (autofill && __builtin_popcount(s.cl) == 8 && s.n < 9u) {
+        const u32 idx = (u32)__builtin_ctz(~s.cl);
+        s.set_sq(idx, s.n);                                      // board[idx] = len(self.moves)
+        s.cl |= 1u << idx;
+        s.set_mv(s.n, idx | (idx << 4));                         // moves.append((idx, idx, len))
+        s.n += 1u;
+    }
+}
+
+__device__ __forceinline__ void cold_pack(const Cold &in, u64 &P, u64 &Q) {
+    Cold s = in;
+    // strip an explicit autofill move (lo == hi, always the last one) back to the implicit form
+    if (s.n >= 1u && s.n <= 9u) {
+        const u32 last = s.mv(s.n - 1u);
+        if ((last & 0xFu) == (last >> 4)) {
+            const u32 idx = last & 0xFu;
+            if (idx < 9u) {
+                s.cl &= ~(1u << idx);
+                s.set_sq(idx, 0xFu);
+            }
+            s.n -= 1u;
+        }
+    }
+    u32 Q0 = 0, last_x = 0;
+    for (u32 t = 0; t < s.n && t < 9u; ++t) {
+        const u32 m = s.mv(t);
+        last_x = ((m & 0xFu) ^ (m >> 4)) & 0xFu;
+        Q0 ^= rotr32(last_x << 2, 4u * t + 4u);                  // as the step kernel appends it
+    }
+    const u64 sqc = (s.sq & 0xFFFFFFFFFull) ^ 0xFFFFFFFFFull;
+    const u32 P1f = (s.n << P1_N_SHIFT) | (((u32)(s.comps >> 32) & 0xFu) << P1_CHI_SHIFT) |
+                    (last_x << P1_LX_SHIFT) | (s.cl << P1_CL_SHIFT) | (s.done ? P1_DONE : 0u);
+    P = (sqc << 2) | ((u64)P1f << 32);
+    Q = (u64)Q0 | ((u64)(u32)s.comps << 32);
+}
+
+// one line of board.py:85-110: p1/p2 = min over completed lines of the max round in the line
+__device__ __forceinline__ void cold_line(const Cold &s, u32 X, u32 O, u32 L, int &p1, int &p2) {
+    int mx = -1;
+    for (u32 v = 0; v < 9; ++v)
+        if (L >> v & 1u) mx = max(mx, (int)s.sqv(v));
+    const bool c1 = (X & L) == L, c2 = !c1 && (O & L) == L;     // selects, not a choice of address:
+    p1 = c1 ? min(p1, mx) : p1;                                  // keeps p1/p2 in registers
+    p2 = c2 ? min(p2, mx) : p2;
+}
+
+__device__ __forceinline__ void cold_check_win(const Cold &s, int &p1, int &p2) {
+    // board.py:71-115, lines in the reference's order (rows, cols, 2-4-6, 0-4-8)
+    u32 X = 0, O = 0;
+    for (u32 v = 0; v < 9; ++v)
+        if (s.cl >> v & 1u) { if (s.sqv(v) & 1u) O |= 1u << v; else X |= 1u << v; }
+    p1 = 10;
+    p2 = 10;
+    cold_line(s, X, O, 0x007u, p1, p2);
+    cold_line(s, X, O, 0x038u, p1, p2);
+    cold_line(s, X, O, 0x1C0u, p1, p2);
+    cold_line(s, X, O, 0x049u, p1, p2);
+    cold_line(s, X, O, 0x092u, p1, p2);
+    cold_line(s, X, O, 0x124u, p1, p2);
+    cold_line(s, X, O, 0x054u, p1, p2);
+    cold_line(s, X, O, 0x111u, p1, p2);
+    if (p1 >= 10) p1 = -1;
+    if (p2 >= 10) p2 = -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The MCTS-side kernels (node_info / expand / rollout / check_win) do not go through the generic
+// `Cold` form: what they need is computed straight from the packed words.
+struct Lite {
+    u64 P;          // plane P with the implicit autofill materialised in the nibbles
+    u32 cl;         // classical mask, autofilled square included
+    u32 n;          // len(moves), autofill move included
+    u32 n_real;     // moves played (the autofill move is not one)
+};
+
+__device__ __forceinline__ Lite lite_unpack(u64 P) {
+    Lite s;
+    const u32 P1 = (u32)(P >> 32);
+    s.cl = (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    s.n_real = s.n = (P1 >> P1_N_SHIFT) & 0xFu;
+    if (__builtin_popcount(s.cl) == 8 && s.n < 9u) {                 // board.py:22-25, implicit in the state
+        const u32 idx = (u32)__builtin_ctz(~s.cl);
+        P |= (u64)(15u - s.n) << (4u * idx + 2u);                    // its code was 0 (isolated square)
+        s.cl = 0x1FFu;
+        s.n += 1u;
+    }
+    s.P = P;
+    return s;
+}
+
+// Board.check_win (board.py:71-115) without visiting lines: p1_round = min over completed X lines of
+// the line's latest round = the smallest m in {4,6,8} such that the X squares of round <= m contain
+// a line (three X marks need rounds 0,2,4 at least); likewise p2_round over {5,7}.  "round <= m" is
+// "code >= 15-m" on the complemented nibbles, tested for eight squares at once (classical codes are
+// 7..15: bit 3 set and low three bits >= T-8 <=> adding 16-T carries into bit 3).
+__device__ __forceinline__ void fast_check_win(const Lite &s, int &p1, int &p2) {
+    const u32 W = (u32)(s.P >> 2);                                   // codes of squares 0..7
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+    const u32 par = W & 0x11111111u;                                 // odd code = even round = X
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((c8 & 1u) << 8);
+    const u32 X = s.cl & even, O = s.cl & ~even;
+    u32 ge[3];
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k) {                                    // code >= 9, 10, 11  <=>  round <= 6, 5, 4
+        const u32 T = 9u + k;
+        const u32 y = ((W & 0x77777777u) + 0x11111111u * (16u - T)) & W & 0x88888888u;
+        ge[k] = ((__builtin_amdgcn_udot8(y, 0x00008421u, 0u, false) |
+                  (__builtin_amdgcn_udot8(y, 0x84210000u, 0u, false) << 4)) >> 3) | ((c8 >= T ? 1u : 0u) << 8);
+    }
+    const uint8_t *lut = g_line_lut.b;
+    p1 = lut[X & ge[2]] ? 4 : (lut[X & ge[0]] ? 6 : (lut[X] ? 8 : -1));
+    p2 = lut[O & ge[1]] ? 5 : (lut[O] ? 7 : -1);
+}
+
+// GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal = a line or
+// nine moves.  Through the workgroup's LDS line table (the step kernel's: a dword per mask, read at
+// mask * 4): who holds a line takes two gathers; the rounds matter only when both players do
+// (p1 in {4,6,8}, p2 in {5,7}: p1 < p2 <=> p1 == 4, or p1 == 6 and p2 == 7), a branch most waves skip.
+__device__ __forceinline__ void lite_update_winner(const Lite &s, const uint8_t *lut, int &winner, int &terminal) {
+    const u32 W = (u32)(s.P >> 2);
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+    const u32 par = W & 0x11111111u;
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((c8 & 1u) << 8);
+    const u32 X = s.cl & even, O = s.cl & ~even;
+    const u32 *l32 = reinterpret_cast<const u32 *>(lut);
+    const bool hx = l32[X] != 0u, ho = l32[O] != 0u;
+    winner = hx ? 1 : (ho ? 0 : -1);
+    if (hx && ho) {
+        u32 ge[3];
+#pragma unroll
+        for (u32 k = 0; k < 3; ++k) {                                // code >= 9, 10, 11  <=>  round <= 6, 5, 4
+            const u32 T = 9u + k;
+            const u32 y = ((W & 0x77777777u) + 0x11111111u * (16u - T)) & W & 0x88888888u;
+            ge[k] = ((__builtin_amdgcn_udot8(y, 0x00008421u, 0u, false) |
+                      (__builtin_amdgcn_udot8(y, 0x84210000u, 0u, false) << 4)) >> 3) | ((c8 >= T ? 1u : 0u) << 8);
+        }
+        winner = (l32[X & ge[2]] != 0u || (l32[X & ge[0]] != 0u && l32[O & ge[1]] == 0u)) ? 1 : 0;
+    }
+    terminal = (s.n == 9u || hx || ho) ? 1 : 0;
+}
+
+// GameState.actions (mcts.py:20-27) in ind2move order (mcts.py:339-343): the pairs (i, j > i) of
+// row i are the empty squares above i, eight rows at offsets 0, 8, 15, 21, 26, 30, 33, 35
+__device__ __forceinline__ u64 fast_legal_mask(u32 cl) {
+    const u32 E = ~cl & 0x1FFu;
+    u64 m = 0;
+    u32 off = 0;
+#pragma unroll
+    for (u32 i = 0; i < 8; ++i) {
+        m |= (u64)((E >> i & 1u) ? (E >> (i + 1u)) : 0u) << off;
+        off += 8u - i;
+    }
+    return m;
+}
+
+// the same as a table over the nine classical bits, for kernels that have an LDS copy of it
+__host__ __device__ constexpr u64 legal_mask_of(u32 cl) {
+    const u32 E = ~cl & 0x1FFu;
+    u64 m = 0;
+    u32 off = 0;
+    for (u32 i = 0; i < 8; ++i) {
+        m |= (u64)((E >> i & 1u) ? (E >> (i + 1u)) : 0u) << off;
+        off += 8u - i;
+    }
+    return m;
+}
+struct LegalLut {
+    u64 m[512];
+    constexpr LegalLut() : m() {
+        for (u32 cl = 0; cl < 512; ++cl) m[cl] = legal_mask_of(cl);
+    }
+};
+__device__ const LegalLut g_legal_lut = LegalLut();
+template <int BLOCK>
+__device__ inline void fill_legal_lut(u64 *dst) {
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) dst[w] = g_legal_lut.m[w];
+}
+
+// GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
+// (Objects/tupleobject.c tuplehash, xxHash-style; hash(int) = the int, hash(-1) = -2).  One
+// accumulator step is acc = rotl(acc + lane * P2, 31) * P1; the products lane * P2 are tabulated
+// for the ten board values and for the hash of every possible move tuple (lo, hi, round).
+constexpr u64 PYH_P1 = 11400714785074694791ull, PYH_P2 = 14029467366897019727ull, PYH_P5 = 2870177450012600261ull;
+__host__ __device__ constexpr u64 pyh_step(u64 acc, u64 lane_times_p2) {
+    acc += lane_times_p2;
+    acc = (acc << 31) | (acc >> 33);
+    return acc * PYH_P1;
+}
+__host__ __device__ constexpr u64 pyh_fin(u64 acc, u64 len) {
+    acc += len ^ (PYH_P5 ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+struct PyHashLut {
+    u64 board[10];          // [v + 1] for Board.board value v = -1..8
+    u64 move[9][9][9];      // [a][b][round] for the move on squares {a, b}, either order
+    constexpr PyHashLut() : board(), move() {
+        board[0] = (u64)(long long)-2 * PYH_P2;
+        for (u64 v = 0; v < 9; ++v) board[v + 1] = v * PYH_P2;
+        for (u64 a = 0; a < 9; ++a)
+            for (u64 b = 0; b < 9; ++b)
+                for (u64 t = 0; t < 9; ++t) {
+                    u64 in = PYH_P5;
+                    in = pyh_step(in, (a < b ? a : b) * PYH_P2);    // Board.moves holds (lo, hi, round)
+                    in = pyh_step(in, (a < b ? b : a) * PYH_P2);
+                    in = pyh_step(in, t * PYH_P2);
+                    move[a][b][t] = pyh_fin(in, 3) * PYH_P2;
+                }
+    }
+};
+__device__ const PyHashLut g_pyhash_lut = PyHashLut();
+constexpr u32 PYHASH_LUT_WORDS = 10 + 729;          // u64 entries: board[10] then move[9][9][9]
+
+// the table is gathered 9 + n times per board with a different entry in every lane: it is served
+// from an LDS copy (5.9 KB per workgroup), not from the vector cache
+template <int BLOCK>
+__device__ inline void fill_pyhash_lut(u64 *dst) {
+    const u64 *src = reinterpret_cast<const u64 *>(&g_pyhash_lut);
+    for (u32 w = threadIdx.x; w < PYHASH_LUT_WORDS; w += BLOCK) dst[w] = src[w];
+}
+
+__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0, const u64 *tbl) {
+    u64 acc = PYH_P5;
+    const u32 W = (u32)(s.P >> 2);                                  // codes of squares 0..7
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) {
+        const u32 c = v < 8u ? (W >> (4u * v)) & 0xFu : c8;
+        acc = pyh_step(acc, tbl[(s.cl >> v & 1u) ? 16u - c : 0u]);  // board[value + 1], value = 15 - c
+    }
+    // moves in round order: round t is held by the one square whose code is 15 - t (zero nibble of
+    // W ^ 0x1111_1111 * code; the lowest flag of the borrow trick is always a true zero; no flag =
+    // square 8), and is (c, c ^ x_t).  x nibbles: round 0 in bits 0..3 of Qr, round t >= 1 at 32 - 4t.
+    const u32 last_x = (P1_stored >> P1_LX_SHIFT) & 0xFu;
+    const u32 Qr = rotr32(Q0, 30u) ^ (s.n_real == 9u ? last_x : 0u);  // round 8's x was XORed onto round 0's
+    const u32 n8 = min(s.n, 8u);
+    u32 kk = 0xFFFFFFFFu, sh = 0u;
+    for (u32 t = 0; t < n8; ++t) {                                  // (an autofill move is always round 8)
+        const u32 z = W ^ kk;
+        const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
+        const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
+        const u32 o = min(c ^ ((Qr >> sh) & 0xFu), 8u);             // (only a corrupted import could exceed 8)
+        acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + t]);
+        kk -= 0x11111111u;
+        sh = (sh - 4u) & 31u;
+    }
+    if (s.n == 9u) {
+        const u32 z = W ^ 0x77777777u;
+        const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
+        const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
+        const u32 o = min(c ^ (s.n_real == 9u ? last_x : 0u), 8u);  // autofill = (idx, idx)
+        acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + 8u]);
+    }
+    return (int64_t)pyh_fin(acc, 9u + s.n);
+}
+
+}  // namespace
+
+#endif  // QTTT_BOARD_FORMS_H

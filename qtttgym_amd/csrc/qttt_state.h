@@ -1,0 +1,220 @@
+// qttt_state.h — the packed 16-byte board, its loads and stores, and the small tables every kernel
+// shares (3-in-a-row table, counter hash, uniform-legal policy table).  Layout: see qttt_kernels.hip.
+#ifndef QTTT_STATE_H
+#define QTTT_STATE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "qttt.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#ifndef QTTT_BLOCK
+#define QTTT_BLOCK 512
+#endif
+#define QTTT_DEFAULT_BPL 2
+#define QTTT_STATE_BYTES 16
+
+
+namespace {
+
+constexpr u32 SLOT_LSB = 0x08040201u;      // bit 0 of each 9-bit comps slot
+
+// P1 = high word of plane P
+constexpr u32 P1_N_SHIFT = 8, P1_CHI_SHIFT = 12, P1_LX_SHIFT = 16, P1_CL_SHIFT = 22;
+constexpr u32 P1_DONE = 0x80000000u;
+
+struct Planes {
+    u64 *P;
+    u64 *Q;
+};
+
+// plane stride: n rounded up to 64 boards, so every plane starts 512-byte aligned
+__host__ __device__ inline int64_t plane_stride(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
+__host__ __device__ inline Planes planes(void *state, int64_t n) {
+    Planes p;
+    p.P = reinterpret_cast<u64 *>(state);
+    p.Q = p.P + plane_stride(n);
+    return p;
+}
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+// same-size raw integer type for a Vec, so cache-policy builtins (which want scalars / ext vectors)
+// can be applied to it
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+template <int BYTES> struct RawOf;
+template <> struct RawOf<1> { typedef uint8_t type; };
+template <> struct RawOf<2> { typedef uint16_t type; };
+template <> struct RawOf<4> { typedef u32 type; };
+template <> struct RawOf<8> { typedef u32x2 type; };
+template <> struct RawOf<16> { typedef u32x4 type; };
+template <> struct RawOf<32> { typedef u32x8 type; };
+
+// Every access of the step kernel is streaming within a launch (each byte is touched once) and L2
+// contents do not survive to the next launch, so all of them carry the non-temporal hint
+// (measured, stores only: nt 7.6 / sc1 7.9 / plain 8.2 us per 1 M-board launch)
+template <typename V>
+__device__ __forceinline__ V load_stream(const V *p) {
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+    V v;
+    __builtin_memcpy(&v, &r, sizeof(V));
+    return v;
+}
+template <typename V>
+__device__ __forceinline__ void store_stream(V *p, const V &v) {
+    typedef typename RawOf<sizeof(V)>::type R;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+}
+
+__device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
+// v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xFFFFFFFF for 0
+__device__ __forceinline__ u32 ffbl_raw(u32 x) {
+    u32 r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+#ifdef QTTT_DEBUG_STAMPS
+__device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench stamps)
+#endif
+
+// ------------------------------------------------------------------ 3-in-a-row lookup table
+// line_lut[m] = 0x7F iff the 9-bit square mask m contains one of the 8 lines of board.py:85-110.
+// The LDS copy keeps one entry per DWORD (LINE_LUT_BYTES = 2 KB), because every mask of the hot
+// path lives "times four" (the nibbles sit at bit 4v+2): the byte offset into the table is the
+// mask itself, no shift.
+__host__ __device__ constexpr bool mask_has_line(u32 m) {
+    return (m & 0x007u) == 0x007u || (m & 0x038u) == 0x038u || (m & 0x1C0u) == 0x1C0u ||
+           (m & 0x049u) == 0x049u || (m & 0x092u) == 0x092u || (m & 0x124u) == 0x124u ||
+           (m & 0x054u) == 0x054u || (m & 0x111u) == 0x111u;
+}
+
+struct LineLut {
+    uint8_t b[512];
+    constexpr LineLut() : b() {
+        for (u32 m = 0; m < 512; ++m) b[m] = mask_has_line(m) ? 0x7F : 0;   // 0x7F << 23 = 1.0f
+    }
+};
+__constant__ LineLut g_line_lut = LineLut();
+constexpr u32 LINE_LUT_BYTES = 2048;
+
+// The LDS copy is COMPUTED (thread w makes entry w, a dozen instructions once per launch), not
+// loaded: a global load in front of the workgroup barrier would tie the barrier — and with it every
+// wave of the workgroup — to the slowest wave's state loads (its `s_waitcnt vmcnt(0)` covers them
+// too).  Computed, the barrier is passed while the loads are still in flight and every wave then
+// waits for its own data only: 7.2 – 7.4 against 7.45 – 7.6 us per 1 M boards, 3.8 against 4.05 us
+// at 262 144 (tools/stepbench, interleaved).
+__device__ __forceinline__ u32 line_lut_entry(u32 m) {
+    const u32 rows = m & (m >> 1) & (m >> 2) & 0x049u;                 // 0-1-2, 3-4-5, 6-7-8
+    const u32 cols = m & (m >> 3) & (m >> 6) & 0x007u;                 // 0-3-6, 1-4-7, 2-5-8
+    const bool diag = (m & 0x111u) == 0x111u || (m & 0x054u) == 0x054u;
+    return ((rows | cols) != 0u || diag) ? 0x7Fu : 0u;
+}
+template <int BLOCK>
+__device__ inline void fill_line_lut_nosync(uint8_t *lut) {
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = line_lut_entry(w);
+}
+template <int BLOCK>
+__device__ inline void fill_line_lut(uint8_t *lut) {
+    fill_line_lut_nosync<BLOCK>(lut);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ counter hash (the build's
+// synthetic-input spec)
+__host__ __device__ inline u32 lowbias32(u32 x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline u64 launch_key(u64 seed, u32 step_idx) {
+    return splitmix64(seed ^ ((u64)step_idx * 0xD1B54A32D192ED03ull));
+}
+__host__ __device__ inline u32 fold_id(u64 board_id) {
+    u32 f = (u32)board_id;
+    u32 h = (u32)(board_id >> 32);
+    if (h) f ^= h * 0x9E3779B9u;           // never taken below 2^32 boards: no multiply on the hot path
+    return f;
+}
+// top bit of lowbias32(x): the final xor-shift cannot change bit 31, so it is skipped
+__device__ inline u32 collapse_bit_of(u32 x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    return x >> 31;
+}
+
+// ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
+// rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4.
+// nth5[m][r] / nth4[m][r]: index of the r-th set bit of a 5-bit / 4-bit mask: the r-th set bit of the
+// 9-bit empty-square mask is looked up in its low five bits or, past their population, in its
+// high four.  584 bytes in all, so that filling it per workgroup costs next to nothing.
+struct PolicyLut {
+    uint8_t rank_pair[10 * 36];
+    uint8_t nth5[32 * 5];
+    uint8_t nth4[16 * 4];
+    constexpr PolicyLut() : rank_pair(), nth5(), nth4() {
+        for (int e = 0; e < 10; ++e) {
+            int k = 0;
+            for (int i = 0; i < e; ++i)
+                for (int j = i + 1; j < e; ++j) rank_pair[e * 36 + k++] = (uint8_t)(i | (j << 4));
+            for (; k < 36; ++k) rank_pair[e * 36 + k] = 0;
+        }
+        for (int m = 0; m < 32; ++m) {
+            int r = 0;
+            for (int v = 0; v < 5; ++v)
+                if (m >> v & 1) nth5[m * 5 + r++] = (uint8_t)v;
+            for (; r < 5; ++r) nth5[m * 5 + r] = 0;
+        }
+        for (int m = 0; m < 16; ++m) {
+            int r = 0;
+            for (int v = 0; v < 4; ++v)
+                if (m >> v & 1) nth4[m * 4 + r++] = (uint8_t)(5 + v);
+            for (; r < 4; ++r) nth4[m * 4 + r] = 0;
+        }
+    }
+};
+__constant__ PolicyLut g_policy_lut = PolicyLut();
+constexpr u32 POLICY_LUT_WORDS = (10 * 36 + 32 * 5 + 16 * 4) / 4;
+constexpr u32 POLICY_NTH5 = 360, POLICY_NTH4 = 360 + 160;
+
+template <int BLOCK>
+__device__ inline void fill_policy_lut(uint8_t *dst) {
+    const u32 *src = reinterpret_cast<const u32 *>(&g_policy_lut);
+    for (u32 w = threadIdx.x; w < POLICY_LUT_WORDS; w += BLOCK) reinterpret_cast<u32 *>(dst)[w] = src[w];
+}
+
+// the r-th (0-based) set bit of the 9-bit mask `m`
+__device__ __forceinline__ u32 policy_nth(const uint8_t *plut, u32 m, u32 c5, u32 r) {
+    return r < c5 ? (u32)plut[POLICY_NTH5 + (m & 31u) * 5u + r] : (u32)plut[POLICY_NTH4 + (m >> 5) * 4u + (r - c5)];
+}
+
+// the policy's action for a board whose empty-square mask is `empty`, from hash word h2: lo | hi<<8
+__device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32 h2) {
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 k = __umulhi(h2, (e * (e - 1u)) >> 1);
+    const u32 ij = plut[e * 36u + k];
+    const u32 c5 = (u32)__builtin_popcount(empty & 31u);
+    return policy_nth(plut, empty, c5, ij & 0xFu) | (policy_nth(plut, empty, c5, ij >> 4) << 8);
+}
+
+}  // namespace
+
+#endif  // QTTT_STATE_H

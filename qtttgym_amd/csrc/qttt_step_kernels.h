@@ -1,0 +1,201 @@
+// qttt_step_kernels.h — the step kernels: lane per board (the product), wave per board (mapping study),
+// and the T-steps-in-registers replay form.
+#ifndef QTTT_STEP_KERNELS_H
+#define QTTT_STEP_KERNELS_H
+#include "qttt_step_core.h"
+#include "qttt_observation.h"
+
+namespace {
+
+// ====================================================================== the step kernels
+// BPL boards per lane: lane j owns boards [j*BPL, (j+1)*BPL), so every plane is read and written
+// with 16-byte vector accesses that are contiguous across the wave.  Addresses are a block-uniform
+// 64-bit base (scalar unit) plus a 32-bit lane offset.
+// SAMPLE: the action is not read but drawn in the kernel from the uniform-legal policy (and written to
+// `actions` when that is not null) — qttt_sample_actions + qttt_step in one launch.
+// OBS: Env.step returns the observation too (env.py:46,53): it is written from the registers the
+// step already holds, through the LDS tiles above — qttt_step + qttt_observe in one launch.
+// BLOCK: workgroup size, chosen by the host per launch: 1024 for batches that fill the chip with
+// 1024-thread workgroups (7.2-7.5 us instead of 7.6-7.7 per 1 M boards), QTTT_BLOCK = 512 below
+// (262 144 boards: 3.8 us with 512 against 4.9 with 1024, which would leave half the CUs idle).
+template <int BLOCK, int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
+__global__ __launch_bounds__(BLOCK) void step_kernel(
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, uint16_t *__restrict__ actions,
+    const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi, u32 id_base,
+    u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, ObsOut obs, int64_t i_begin,
+    u32 last_groups) {
+    constexpr u32 TILE_BOARDS = BLOCK * BPL;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
+    __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
+    __shared__ __attribute__((aligned(16))) u32 olut[OBS ? OBS_LUT_BYTES / 4 : 4];
+#ifdef QTTT_DEBUG_STAMPS
+    const u64 st0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    typedef Vec<u64, BPL> V64;
+    typedef Vec<u32, BPL> V32;
+    typedef Vec<uint16_t, BPL> V16;
+    typedef Vec<uint8_t, BPL> V8;
+    const int64_t jb = (int64_t)blockIdx.x * BLOCK;                // first lane-group of the block
+    const int64_t ib = i_begin + jb * BPL;                              // first board of the block
+    // lane-groups of this block: every block is full except possibly the last one of the grid
+    const u32 ng = blockIdx.x + 1u == gridDim.x ? last_groups : (u32)BLOCK;
+    const bool active = threadIdx.x < ng;
+    const u32 g = active ? threadIdx.x : 0u;                            // idle lanes re-read group 0
+    // The small tables that are LOADED (policy, observation) are requested first and stored after
+    // the streaming loads have been issued: vector loads return in order, so the wait in front of
+    // the table's LDS store then covers the table word only, not this wave's state.  The line table
+    // is computed.  Either way the workgroup barrier is passed while the state is still in flight.
+    static_assert(!SAMPLE || BLOCK >= (int)POLICY_LUT_WORDS, "one policy-table word per thread");
+    u32 plw = 0, olw = 0;
+    if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) plw = reinterpret_cast<const u32 *>(&g_policy_lut)[threadIdx.x];
+    if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olw = (&g_obs_lut.sel[0][0])[threadIdx.x];
+    V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
+    V64 q = load_stream(&reinterpret_cast<const V64 *>(pQ + ib)[g]);
+    V16 act;
+    V8 bt;
+    if (!SAMPLE) act = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g]);
+    if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
+    fill_line_lut_nosync<BLOCK>(lut);
+    if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) reinterpret_cast<u32 *>(plut)[threadIdx.x] = plw;
+    if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olut[threadIdx.x] = olw;
+    ObsTiles T;
+    if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
+    __syncthreads();
+#ifdef QTTT_DEBUG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (active) {
+        V32 rw;
+        V8 tm;
+        const u32 id0 = id_base + ((u32)jb + g) * BPL;                  // low 32 bits of the global board id
+#pragma unroll
+        for (int k = 0; k < BPL; ++k) {
+            u32 P0 = (u32)p.v[k], P1 = (u32)(p.v[k] >> 32);
+            u32 Q0 = (u32)q.v[k], Q1 = (u32)(q.v[k] >> 32);
+            u32 bit, av;
+            if (SAMPLE) {
+                // the policy sees the board the step will act on: a finished board counts as empty
+                const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
+                const u32 h2 = lowbias32(h1 ^ key_hi);
+                const u32 empty = policy_empty_mask<AUTO_RESET>(P1);
+                av = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
+                act.v[k] = (uint16_t)av;
+                bit = h1 >> 31;
+            } else {
+                av = act.v[k];
+                if (HAS_BITS) bit = bt.v[k] & 1u;
+                else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+            }
+            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
+            p.v[k] = (u64)P0 | ((u64)P1 << 32);
+            q.v[k] = (u64)Q0 | ((u64)Q1 << 32);
+            rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f
+            tm.v[k] = (uint8_t)(P1 >> 31);
+            if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k, olut);
+        }
+        store_stream(&reinterpret_cast<V64 *>(pP + ib)[g], p);
+        store_stream(&reinterpret_cast<V64 *>(pQ + ib)[g], q);
+        if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g], act);
+        store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g], rw);
+        store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g], tm);
+    }
+    if (OBS) {
+        // a wave's boards [64w * BPL, 64(w+1) * BPL) start on a multiple of 4 bytes in every tile
+        if ((64u * BPL) % 4u == 0u && obs_all_phase0(obs, ib)) {
+            const u32 w0 = (threadIdx.x & ~63u) * BPL;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // rows written by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+            if (w0 < ng * BPL) obs_wave_copy_out<TILE_BOARDS>(otile, obs, ib, w0, min(w0 + 64u * BPL, ng * BPL));
+        } else {
+            __syncthreads();
+            obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, ib, ng * BPL);
+        }
+    }
+#ifdef QTTT_DEBUG_STAMPS
+    const u64 st2 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st3 = __builtin_amdgcn_s_memrealtime();
+    if (g_debug_stamps && (threadIdx.x & 63) == 0) {
+        u64 *o = g_debug_stamps + ((int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+#endif
+}
+
+// Mapping study: ONE WAVEFRONT PER BOARD, the mapping BASELINE.json's north_star
+// sketches.  A board's step is a chain of dependent operations on a 9-node graph (validity ->
+// component lookup -> path walk -> collapse -> line test), so whatever the 64 lanes of a wave do
+// with __shfl/__ballot, the wave cannot retire a board faster than one lane can run that chain.
+// This kernel is that lower bound made concrete: lane 0 of every wave runs the same step_core, the
+// other 63 lanes are idle, state is staged through LDS by the workgroup.  Same results as
+// step_kernel (tested); measured beside it in tools/stepbench.
+template <bool HAS_BITS, bool AUTO_RESET>
+__global__ __launch_bounds__(256) void step_wave_per_board_kernel(
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, const uint16_t *__restrict__ actions,
+    const uint8_t *__restrict__ bits, u32 key_fold, u32 id_base, u32 *__restrict__ reward_bits,
+    uint8_t *__restrict__ terminated, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ u64 sP[4], sQ[4];
+    __shared__ u32 sAct[4], sBit[4];
+    fill_line_lut_nosync<256>(lut);
+    const int64_t i0 = (int64_t)blockIdx.x * 4;                   // 4 waves = 4 boards per workgroup
+    if (threadIdx.x < 4 && i0 + threadIdx.x < n) {                 // cooperative tile load into LDS
+        const int64_t i = i0 + threadIdx.x;
+        sP[threadIdx.x] = pP[i];
+        sQ[threadIdx.x] = pQ[i];
+        sAct[threadIdx.x] = actions[i];
+        sBit[threadIdx.x] = HAS_BITS ? bits[i] & 1u : collapse_bit_of((id_base + (u32)i) ^ key_fold);
+    }
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6;
+    const int64_t i = i0 + w;
+    if (i >= n || (threadIdx.x & 63u) != 0u) return;              // lane 0 of each wave owns the board
+    u32 P0 = (u32)sP[w], P1 = (u32)(sP[w] >> 32), Q0 = (u32)sQ[w], Q1 = (u32)(sQ[w] >> 32);
+    const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, sAct[w], sBit[w], lut);
+    pP[i] = (u64)P0 | ((u64)P1 << 32);
+    pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
+    reward_bits[i] = 0x80000000u | (win << 23);
+    terminated[i] = (uint8_t)(P1 >> 31);
+}
+
+// T consecutive steps in ONE launch (qttt_step_many with QTTT_FLAG_FUSED): the boards stay in
+// registers, only the per-step streams move (2 B action in, 5 B reward/terminated out per step), so
+// the loop is VALU-bound and pays one launch instead of T.  Same results as T launches of
+// step_kernel; meant for replay / evaluation where the actions are known up front (a policy that
+// looks at the state between steps needs the one-launch-per-step form).
+template <bool HAS_BITS, bool AUTO_RESET>
+__global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, const uint16_t *__restrict__ actions,
+    const uint8_t *__restrict__ bits, u64 seed, u32 step_idx0, u32 id_hi_fold, u32 id_base,
+    u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, int64_t out_stride, int64_t n,
+    int32_t n_steps) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    fill_line_lut<QTTT_BLOCK>(lut);
+    const int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 P = pP[i], Q = pQ[i];
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
+    const u32 id = id_base + (u32)i;
+    u32 win = 0;
+    for (int32_t t = 0; t < n_steps; ++t) {
+        const u32 act = load_stream(&actions[(int64_t)t * n + i]);
+        u32 bit;
+        if (HAS_BITS) bit = load_stream(&bits[(int64_t)t * n + i]) & 1u;
+        else bit = collapse_bit_of(id ^ ((u32)launch_key(seed, step_idx0 + (u32)t) ^ id_hi_fold));
+        win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, act, bit, lut);
+        if (out_stride != 0 || t == n_steps - 1) {
+            const u32 rwv = 0x80000000u | (win << 23);
+            const uint8_t tmv = (uint8_t)(P1 >> 31);
+            store_stream(&reward_bits[(int64_t)t * out_stride + i], rwv);
+            store_stream(&terminated[(int64_t)t * out_stride + i], tmv);
+        }
+    }
+    pP[i] = (u64)P0 | ((u64)P1 << 32);
+    pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
+}
+
+}  // namespace
+
+#endif  // QTTT_STEP_KERNELS_H
