@@ -353,8 +353,7 @@ def run(args):
             launch_s = ev_med / K
             value = B * K * world / ev_med
             achieved = algo_bytes * B / launch_s / 1e9
-            bpl = int(os.environ.get("QTTT_STEP_BPL", "2"))
-            blk = 1024 if (bpl == 2 and B // 2 >= 512 * 1024) else 512     # qttt_step's own choice (qttt_kernels.hip)
+            bpl, blk = _native.step_launch_shape(B)                        # the library's own choice for this batch
             kernel = ("step_kernel<%d, %d, false, true, false, %s>" % (blk, bpl, "true" if gym else "false")
                       if args.mode in ("replay", "gym") else
                       "step_kernel<%d, %d, false, true, true, false>" % (blk, bpl) if args.mode == "random" else

@@ -127,6 +127,9 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
 #define QTTT_OP_UPDATE_QSTRUCTS 1
 #define QTTT_OP_CHECK_WIN 2
 int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *stream);
+/* The same followed by hipStreamSynchronize(stream): the one entry point that waits (for a caller
+ * whose records live in pinned host memory and are read back right after — the Board façade). */
+int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, void *stream);
 
 /* Synthetic policy for measurement: uniform over legal unordered pairs
  * (GameState.actions rule, mcts.py:20-27) in ind2move order (mcts.py:339-343), index and
@@ -170,9 +173,35 @@ int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t b
  * mask u8[n,36] (nullable).  The reference builds float64; values are 0, 1 and 1/3 rounded to f32. */
 int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *stream);
 
-/* Launch-shape knob of qttt_step (results never depend on it): boards per lane (1, 2 or 4).
- * Process-wide; also settable through QTTT_STEP_BPL before the first call.  `reserved` = 0. */
-int qttt_set_tuning(int boards_per_lane, int reserved);
+/* The buffers of one batch of boards as one caller-owned plain record, so that a per-step host loop
+ * passes 6 arguments instead of 11 - 17 (a Python / ctypes caller is host-bound below ~500 K boards:
+ * DESIGN.md §6).  The library keeps nothing: the record is read during the call only. */
+typedef struct qttt_env {
+    void    *state;                 /* qttt_state_bytes(n) bytes */
+    int64_t  n;
+    int64_t  board_offset;
+    uint64_t seed;
+    uint32_t flags;                 /* QTTT_FLAG_AUTO_RESET */
+    uint32_t reserved;              /* 0 */
+    float   *reward;                /* f32[n] */
+    uint8_t *terminated;            /* u8[n] */
+    int8_t  *classical;             /* the qttt_observe outputs; only read by QTTT_ENV_STEP_OBSERVE */
+    uint8_t *q_p1, *q_p1_len, *q_p2, *q_p2_len, *turn;
+} qttt_env;
+#define QTTT_ENV_STEP         0     /* = qttt_step(actions, bits) */
+#define QTTT_ENV_STEP_OBSERVE 1     /* = qttt_step_observe(actions, bits) */
+#define QTTT_ENV_STEP_RANDOM  2     /* = qttt_step_random(actions_out = actions, nullable); bits ignored */
+int qttt_env_step(const qttt_env *env, uint8_t *actions, const uint8_t *bits, uint32_t step_idx,
+                  int mode, void *stream);
+
+/* Launch shape of qttt_step / qttt_step_observe / qttt_step_random (results never depend on it): boards
+ * per lane (1, 2 or 4) and workgroup size (256, 512 or 1024); 0 = chosen by the library from the batch
+ * size (the default).  Process-wide; also settable through QTTT_STEP_BPL /
+ * QTTT_STEP_BLOCK before the first call. */
+int qttt_set_tuning(int boards_per_lane, int workgroup_size);
+/* The shape a batch of n boards is launched with under the current setting (a caller whose pointers
+ * are not aligned for boards_per_lane elements gets fewer boards per lane). */
+int qttt_step_launch_shape(int64_t n, int *boards_per_lane, int *workgroup_size);
 
 /* One step of every board under that policy with policy and step in ONE kernel: exactly
  * qttt_sample_actions followed by qttt_step(bits = NULL) with the same seed / step_idx /

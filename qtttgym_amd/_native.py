@@ -13,6 +13,17 @@ FLAG_FUSED = 2
 BOARD_RECORD_BYTES = 64
 OP_MAKE_MOVE, OP_UPDATE_QSTRUCTS, OP_CHECK_WIN = 0, 1, 2
 
+class EnvRecord(ctypes.Structure):
+    """include/qttt.h: struct qttt_env."""
+    _fields_ = [("state", ctypes.c_void_p), ("n", ctypes.c_int64), ("board_offset", ctypes.c_int64),
+                ("seed", ctypes.c_uint64), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("reward", ctypes.c_void_p), ("terminated", ctypes.c_void_p), ("classical", ctypes.c_void_p),
+                ("q_p1", ctypes.c_void_p), ("q_p1_len", ctypes.c_void_p), ("q_p2", ctypes.c_void_p),
+                ("q_p2_len", ctypes.c_void_p), ("turn", ctypes.c_void_p)]
+
+
+ENV_STEP, ENV_STEP_OBSERVE, ENV_STEP_RANDOM = 0, 1, 2
+
 # every symbol include/qttt.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,
                                ctypes.c_uint32)
@@ -30,17 +41,27 @@ SIGNATURES = {
     "qttt_export": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_import": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_board_op": (_i32, [_vp, _vp, _i64, _vp]),
+    "qttt_board_op_sync": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
     "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_expand": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_rollout": (_i32, [_vp, _u64, _u32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "qttt_encode": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_set_tuning": (_i32, [_i32, _i32]),
+    "qttt_step_launch_shape": (_i32, [_i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "qttt_env_step": (_i32, [ctypes.POINTER(EnvRecord), _vp, _vp, _u32, _i32, _vp]),
     "qttt_step_random": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _vp]),
     "qttt_hash": (_u64, [_u64, _u64, _u32]),
 }
 
 _lib = None
+
+
+def step_launch_shape(n):
+    """(boards per lane, workgroup size) qttt_step uses for a batch of n boards."""
+    bpl, blk = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().qttt_step_launch_shape(int(n), ctypes.byref(bpl), ctypes.byref(blk)), "qttt_step_launch_shape")
+    return bpl.value, blk.value
 
 
 class QtttNativeError(RuntimeError):

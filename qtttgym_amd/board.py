@@ -14,6 +14,7 @@ import random
 import torch
 
 from . import _native
+from .vec_env import _raw_stream
 
 
 class QEvalClassic:
@@ -63,6 +64,7 @@ class _Staging:
         self.a_out = self.t_out.numpy()
         self.m_in = memoryview(self.a_in)
         self.p_in, self.p_out = self.t_in.data_ptr(), self.t_out.data_ptr()
+        self.op_sync = self.lib.qttt_board_op_sync
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def run(self, board, op, lo=0, hi=0, bit=0, drop_last_move=False):
@@ -93,9 +95,10 @@ class _Staging:
         return self.a_out
 
     def _launch(self):
-        stream = torch.cuda.current_stream(self.device)
-        _native.check(self.lib.qttt_board_op(self.p_in, self.p_out, 1, stream.cuda_stream), "qttt_board_op")
-        stream.synchronize()
+        # launch + hipStreamSynchronize in one call, on the caller's current stream (raw handle)
+        rc = self.op_sync(self.p_in, self.p_out, 1, _raw_stream(self.device.index))
+        if rc:
+            _native.check(rc, "qttt_board_op_sync")
 
 
 _PAD18 = b"\xff" * 18

@@ -53,12 +53,43 @@
 
 namespace {
 
-// tuning knob (bench / profiling): boards per lane of the step kernel (1|2|4).  Initialised from
-// QTTT_STEP_BPL, changeable at run time through qttt_set_tuning().
+// Boards per lane and workgroup size of the step kernel, by batch size.  Measured on MI355X with
+// tools/stepbench (interleaved A/B, profiles/r02/stepbench_block_sweep.txt), us per launch:
+//   boards      (1,256) (1,1024) (2,256) (2,512) (2,1024)
+//   131 072      3.11    3.41     3.36    3.46    4.25
+//   262 144      3.63    3.66     3.90    3.86    4.62
+//   393 216      4.38    4.74     4.61    4.92    4.83
+//   524 288      5.16    4.93     5.30    5.23    5.08
+//   786 432      7.29    6.75     6.59    6.27    6.95
+//   1 048 576    8.84    8.72     7.68    7.37    7.25
+//   1 572 864   12.05   12.75    11.56   11.78   11.39
+//   2 097 152   14.38   16.10    13.53   13.64   14.08
+//   4 194 304   28.40   30.52    27.51   27.78   29.12
+//   16 777 216  103.2   109.0    105.0   107.4   108.5
+// Below ~450 K boards the launch is latency-bound and one board per lane in small workgroups puts the
+// most waves in flight; 1024-thread workgroups win where they fill the chip exactly once (512 K lanes =
+// 2 workgroups on each of the 256 CUs); past that, small workgroups backfill best.
+inline void auto_tuning(int64_t n, int &bpl, int &blk) {
+    if (n <= 448 * 1024) { bpl = 1; blk = 256; }
+    else if (n <= 512 * 1024) { bpl = 1; blk = 1024; }
+    else if (n < 896 * 1024) { bpl = 2; blk = 512; }
+    else if (n <= 1536 * 1024) { bpl = 2; blk = 1024; }
+    else { bpl = 2; blk = 256; }
+}
+// overrides (bench / profiling / tests): boards per lane 1|2|4 and workgroup size 256|512|1024, 0 = by
+// batch size.  Initialised from QTTT_STEP_BPL / QTTT_STEP_BLOCK, changeable through qttt_set_tuning().
 inline int &tuning_bpl() {
     static int v = [] {
-        int k = QTTT_DEFAULT_BPL;
+        int k = 0;
         if (const char *e = getenv("QTTT_STEP_BPL")) { int q = atoi(e); if (q == 1 || q == 2 || q == 4) k = q; }
+        return k;
+    }();
+    return v;
+}
+inline int &tuning_block() {
+    static int v = [] {
+        int k = 0;
+        if (const char *e = getenv("QTTT_STEP_BLOCK")) { int q = atoi(e); if (q == 256 || q == 512 || q == 1024) k = q; }
         return k;
     }();
     return v;
@@ -67,8 +98,6 @@ inline int &tuning_bpl() {
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
 inline int cold_grid_for(int64_t n) { return (int)((n + QTTT_COLD_BLOCK - 1) / QTTT_COLD_BLOCK); }
 inline int blocks_for(int64_t n_groups, int block) { return (int)((n_groups + block - 1) / block); }
-// lane-groups from which qttt_step uses 1024-thread workgroups: 512 such workgroups = 16 waves on every SIMD pair
-#define QTTT_BIG_BLOCK_MIN_GROUPS (512 * 1024)
 
 inline int launch_status() {
     hipError_t e = hipGetLastError();
@@ -89,10 +118,24 @@ int qttt_debug_set_stamps(void *buf) {
 }
 #endif
 
-int qttt_set_tuning(int boards_per_lane, int reserved) {
-    (void)reserved;
-    if (!(boards_per_lane == 1 || boards_per_lane == 2 || boards_per_lane == 4)) return QTTT_ERR_SIZE;
+int qttt_set_tuning(int boards_per_lane, int workgroup_size) {
+    if (!(boards_per_lane == 0 || boards_per_lane == 1 || boards_per_lane == 2 || boards_per_lane == 4)) return QTTT_ERR_SIZE;
+    if (!(workgroup_size == 0 || workgroup_size == 256 || workgroup_size == 512 || workgroup_size == 1024)) return QTTT_ERR_SIZE;
     tuning_bpl() = boards_per_lane;
+    tuning_block() = workgroup_size;
+    return 0;
+}
+
+int qttt_step_launch_shape(int64_t n, int *boards_per_lane, int *workgroup_size) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (!boards_per_lane || !workgroup_size) return QTTT_ERR_NULL;
+    int bpl, blk;
+    auto_tuning(n, bpl, blk);
+    if (tuning_bpl()) { bpl = tuning_bpl(); blk = QTTT_BLOCK; }
+    if (tuning_block()) blk = tuning_block();
+    if (bpl == 4) blk = QTTT_BLOCK;
+    *boards_per_lane = bpl;
+    *workgroup_size = blk;
     return 0;
 }
 
@@ -128,8 +171,10 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     uint16_t *a16 = reinterpret_cast<uint16_t *>(actions);
     u32 *rb = reinterpret_cast<u32 *>(reward);
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
+    int bpl_pref, blk_sel;
+    qttt_step_launch_shape(n, &bpl_pref, &blk_sel);
     // widest boards-per-lane the caller's pointers are aligned for (the planes always are)
-    int bpl_max = obs ? (tuning_bpl() > 2 ? 2 : tuning_bpl()) : tuning_bpl();   // the tiles are sized for <= 2
+    int bpl_max = obs ? (bpl_pref > 2 ? 2 : bpl_pref) : bpl_pref;              // the tiles are sized for <= 2
     auto aligned = [&](int k) {
         return ((uintptr_t)actions % (2u * k)) == 0 && ((uintptr_t)reward % (4u * k)) == 0 &&
                ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
@@ -140,11 +185,12 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     hipLaunchKernelGGL((step_kernel<BLK, BPL, HB, AR, SM, OB>), dim3(blocks_for(NG, BLK)), dim3(BLK), 0, s, \
                        p.P, p.Q, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated, oo,         \
                        (int64_t)(I0), (u32)((NG) - (int64_t)(blocks_for(NG, BLK) - 1) * (BLK)))
-    // workgroup size: 1024 threads once that still gives every CU two workgroups' worth of waves
+    // workgroup size as chosen above; four boards per lane exists with 512 threads only
 #define QTTT_LAUNCH(BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                              \
     do {                                                                                              \
-        if ((BPL) == 2 && (NG) >= (int64_t)QTTT_BIG_BLOCK_MIN_GROUPS) QTTT_LAUNCH_B(1024, 2, HB, AR, SM, OB, I0, NG, KF, IDB); \
-        else QTTT_LAUNCH_B(QTTT_BLOCK, BPL, HB, AR, SM, OB, I0, NG, KF, IDB);                          \
+        if ((BPL) == 4 || blk_sel == QTTT_BLOCK) QTTT_LAUNCH_B(QTTT_BLOCK, BPL, HB, AR, SM, OB, I0, NG, KF, IDB); \
+        else if (blk_sel == 1024) QTTT_LAUNCH_B(1024, ((BPL) == 4 ? 2 : (BPL)), HB, AR, SM, OB, I0, NG, KF, IDB); \
+        else QTTT_LAUNCH_B(256, ((BPL) == 4 ? 2 : (BPL)), HB, AR, SM, OB, I0, NG, KF, IDB);             \
     } while (0)
 #define QTTT_DISPATCH(BPL, I0, NG, KF, IDB)                                                           \
     do {                                                                                              \
@@ -231,6 +277,25 @@ int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t boar
                      int64_t n, void *stream) {
     return launch_step(state, actions_out, nullptr, seed, step_idx, board_offset, flags, reward,
                        terminated, n, stream, true, nullptr);
+}
+
+int qttt_env_step(const qttt_env *e, uint8_t *actions, const uint8_t *bits, uint32_t step_idx, int mode,
+                  void *stream) {
+    if (!e) return QTTT_ERR_NULL;
+    switch (mode) {
+    case QTTT_ENV_STEP:
+        return qttt_step(e->state, actions, bits, e->seed, step_idx, e->board_offset, e->flags, e->reward,
+                         e->terminated, e->n, stream);
+    case QTTT_ENV_STEP_OBSERVE:
+        return qttt_step_observe(e->state, actions, bits, e->seed, step_idx, e->board_offset, e->flags, e->reward,
+                                 e->terminated, e->classical, e->q_p1, e->q_p1_len, e->q_p2, e->q_p2_len, e->turn,
+                                 e->n, stream);
+    case QTTT_ENV_STEP_RANDOM:
+        return qttt_step_random(e->state, e->seed, step_idx, e->board_offset, e->flags, actions, e->reward,
+                                e->terminated, e->n, stream);
+    default:
+        return QTTT_ERR_SIZE;
+    }
 }
 
 int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
@@ -321,6 +386,13 @@ int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *st
     hipLaunchKernelGGL(board_op_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        (const uint8_t *)records_in, (uint8_t *)records_out, n);
     return launch_status();
+}
+
+int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, void *stream) {
+    const int rc = qttt_board_op(records_in, records_out, n, stream);
+    if (rc) return rc;
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,

@@ -13,7 +13,6 @@ typedef unsigned int u32;
 #ifndef QTTT_BLOCK
 #define QTTT_BLOCK 512
 #endif
-#define QTTT_DEFAULT_BPL 2
 #define QTTT_STATE_BYTES 16
 
 

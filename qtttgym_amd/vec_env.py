@@ -5,10 +5,18 @@ observ / turn / action_space / observation_space, returning tensors of leading d
 All arithmetic happens in libqttt_hip.so (include/qttt.h); torch is used for device memory
 and streams only.
 """
+import ctypes
+
 import torch
 
 from . import _native
 from .spaces import reference_action_space, reference_observation_space
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+if _raw_stream is None:                                   # older torch: the documented, slower way
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
 
 
 def _ptr(t):
@@ -41,11 +49,40 @@ class VecEnv:
             self._terminated = torch.empty(n, dtype=torch.bool, device=self.device)
             self._truncated = torch.zeros(n, dtype=torch.bool, device=self.device)  # env.py:52
         self._obs = None
+        self._bind_outputs()
         self.reset()
 
     # ------------------------------------------------------------------ helpers
+    def _bind_outputs(self):
+        """Addresses of the environment's own output buffers, looked up once (the per-step calls are
+        host-bound below ~500 K boards: every data_ptr() and context switch saved is throughput)."""
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._p_reward, self._p_term = self._reward.data_ptr(), self._terminated.data_ptr()
+        self._p_obs = None
+        # include/qttt.h struct qttt_env: the per-step calls then pass 6 arguments instead of 11 - 17
+        self._rec = _native.EnvRecord(state=self.state.data_ptr(), n=self.num_envs, reward=self._p_reward,
+                                      terminated=self._p_term)
+        self._rec_ref = ctypes.byref(self._rec)
+        self._env_step = self._lib.qttt_env_step
+
+    def _record(self):
+        """The qttt_env record with the fields a caller may have changed since the last step."""
+        r = self._rec
+        r.state = self.state.data_ptr()
+        r.board_offset, r.seed, r.flags = self.board_offset, self.seed, self._flags()
+        return self._rec_ref
+
+    def _launch(self, fn, *args):
+        """Calls into the library with this environment's device current."""
+        if torch.cuda.current_device() == self._dev_index:
+            return fn(*args)
+        with torch.cuda.device(self.device):
+            return fn(*args)
+
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """The caller's current stream on this environment's device, as a raw hipStream_t
+        (torch.cuda.current_stream(dev).cuda_stream costs ~3 us per call, the raw lookup ~0.1)."""
+        return _raw_stream(self._dev_index)
 
     def _flags(self):
         return _native.FLAG_AUTO_RESET if self.auto_reset else 0
@@ -90,12 +127,10 @@ class VecEnv:
         if bits is not None and (bits.dtype != torch.uint8 or not bits.is_contiguous()
                                  or bits.device != self.state.device or bits.numel() != n):
             raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
-        with torch.cuda.device(self.device):
-            rc = self._lib.qttt_step(self.state.data_ptr(), actions.data_ptr(), _ptr(bits), self.seed,
-                                     self.step_idx, self.board_offset, self._flags(),
-                                     self._reward.data_ptr(), self._terminated.data_ptr(), n,
-                                     self._stream())
-        _native.check(rc, "qttt_step")
+        rc = self._launch(self._env_step, self._record(), actions.data_ptr(), _ptr(bits), self.step_idx,
+                          _native.ENV_STEP, self._stream())
+        if rc:
+            _native.check(rc, "qttt_step")
         self.step_idx += 1
         return self._reward, self._terminated
 
@@ -107,11 +142,10 @@ class VecEnv:
         if actions_out is not None and (actions_out.dtype != torch.uint8 or not actions_out.is_contiguous()
                                         or actions_out.numel() != 2 * n or actions_out.device != self.state.device):
             raise ValueError("actions_out must be a contiguous uint8 device tensor of shape (N, 2)")
-        with torch.cuda.device(self.device):
-            rc = self._lib.qttt_step_random(self.state.data_ptr(), self.seed, self.step_idx, self.board_offset,
-                                            self._flags(), _ptr(actions_out), self._reward.data_ptr(),
-                                            self._terminated.data_ptr(), n, self._stream())
-        _native.check(rc, "qttt_step_random")
+        rc = self._launch(self._env_step, self._record(), _ptr(actions_out), None, self.step_idx,
+                          _native.ENV_STEP_RANDOM, self._stream())
+        if rc:
+            _native.check(rc, "qttt_step_random")
         self.step_idx += 1
         return self._reward, self._terminated
 
@@ -169,6 +203,11 @@ class VecEnv:
                     "classical": torch.empty((n, 9), dtype=torch.int8, device=dev),
                     "turn": torch.empty(n, dtype=torch.uint8, device=dev),
                 }
+            o = self._obs
+            self._p_obs = tuple(o[k].data_ptr() for k in ("classical", "q_states_p1", "q_states_p1_len",
+                                                          "q_states_p2", "q_states_p2_len", "turn"))
+            r = self._rec
+            r.classical, r.q_p1, r.q_p1_len, r.q_p2, r.q_p2_len, r.turn = self._p_obs
         return self._obs
 
     def step_observe_raw(self, actions, bits=None):
@@ -183,15 +222,10 @@ class VecEnv:
                                  or bits.device != self.state.device or bits.numel() != n):
             raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
         o = self._obs_buffers()
-        with torch.cuda.device(self.device):
-            rc = self._lib.qttt_step_observe(self.state.data_ptr(), actions.data_ptr(), _ptr(bits), self.seed,
-                                             self.step_idx, self.board_offset, self._flags(),
-                                             self._reward.data_ptr(), self._terminated.data_ptr(),
-                                             o["classical"].data_ptr(), o["q_states_p1"].data_ptr(),
-                                             o["q_states_p1_len"].data_ptr(), o["q_states_p2"].data_ptr(),
-                                             o["q_states_p2_len"].data_ptr(), o["turn"].data_ptr(), n,
-                                             self._stream())
-        _native.check(rc, "qttt_step_observe")
+        rc = self._launch(self._env_step, self._record(), actions.data_ptr(), _ptr(bits), self.step_idx,
+                          _native.ENV_STEP_OBSERVE, self._stream())
+        if rc:
+            _native.check(rc, "qttt_step_observe")
         self.step_idx += 1
         return o, self._reward, self._terminated
 
@@ -297,6 +331,7 @@ class VecEnv:
             env._terminated = torch.empty(n, dtype=torch.bool, device=env.device)
             env._truncated = torch.zeros(n, dtype=torch.bool, device=env.device)
         env._obs = None
+        env._bind_outputs()
         return env
 
     def node_info(self):

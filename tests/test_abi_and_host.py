@@ -39,6 +39,21 @@ def test_state_bytes_and_hash_are_host_callable():
         assert L.qttt_hash(seed, bid, step) == oracle.hash64(seed, bid, step)
 
 
+def test_env_record_call_validates_before_touching_the_device():
+    """qttt_env_step (the struct qttt_env form of the per-step calls): argument errors come back as
+    codes without any device work."""
+    import ctypes
+    from qtttgym_amd import _native
+    L = _native.lib()
+    assert ctypes.sizeof(_native.EnvRecord) == 104                     # include/qttt.h struct qttt_env, LP64
+    assert L.qttt_env_step(None, None, None, 0, _native.ENV_STEP, None) == -1          # QTTT_ERR_NULL
+    rec = _native.EnvRecord(n=0)
+    assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, 7, None) == -2            # unknown mode: QTTT_ERR_SIZE
+    assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, _native.ENV_STEP, None) == 0    # n = 0: nothing to do
+    rec.n = -5
+    assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, _native.ENV_STEP_RANDOM, None) == -2
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "qtttgym_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -36,21 +36,27 @@ def _assert_obs_equals_oracle(obs, ob, tag=""):
 
 @pytest.fixture
 def tuning():
-    """qttt_set_tuning is process-wide: always put the default (2 boards per lane) back."""
+    """qttt_set_tuning is process-wide: always put the default (shape chosen by batch size) back."""
     from qtttgym_amd import _native
     L = _native.lib()
     yield L.qttt_set_tuning
-    assert L.qttt_set_tuning(2, 0) == 0
+    assert L.qttt_set_tuning(0, 0) == 0
 
 
-@pytest.mark.parametrize("bpl", [1, 2, 4])
+@pytest.mark.parametrize("bpl,blk", [(1, 0), (2, 0), (4, 0), (1, 256), (2, 256), (1, 1024), (2, 1024), (0, 0)])
 @pytest.mark.parametrize("n", [1, 3, 64, 65, 257, 4099, 262144])
-def test_every_boards_per_lane_setting_vs_oracle(tuning, bpl, n):
-    """qttt_set_tuning(1|2|4) are exported ABI: each launch shape (plus its ragged tail of
-    n mod bpl boards) is the same function as the oracle, with and without auto-reset."""
-    from qtttgym_amd import VecEnv
-    assert tuning(bpl, 0) == 0
-    assert tuning(3, 0) != 0 and tuning(0, 0) != 0
+def test_every_launch_shape_vs_oracle(tuning, bpl, blk, n):
+    """qttt_set_tuning(boards per lane 1|2|4, workgroup size 256|512|1024; 0 = by batch size) is exported
+    ABI: each launch shape (plus its ragged tail of n mod bpl boards) is the same function as the
+    oracle, with and without auto-reset."""
+    from qtttgym_amd import VecEnv, _native
+    assert tuning(bpl, blk) == 0
+    assert tuning(3, 0) != 0 and tuning(2, 128) != 0 and tuning(-1, 0) != 0
+    shape = _native.step_launch_shape(n)
+    if bpl:
+        assert shape == (bpl, 512 if bpl == 4 else (blk or 512))
+    else:
+        assert shape == ((1, 256) if n <= 448 * 1024 else (2, 1024))
     for auto_reset in (False, True):
         seed, off = 77 + bpl, 11 * n
         env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
@@ -64,6 +70,27 @@ def test_every_boards_per_lane_setting_vs_oracle(tuning, bpl, n):
             assert np.array_equal(_np(reward).view(np.uint32), r_or.view(np.uint32)), (t, auto_reset)
             assert np.array_equal(_np(term).astype(np.uint8), t_or), (t, auto_reset)
         _assert_same_as_oracle(env, ob, (bpl, n, auto_reset))
+
+
+@pytest.mark.parametrize("n,shape", [(450001, (1, 256)), (520001, (1, 1024)), (600001, (2, 512)),
+                                     (1048577, (2, 1024)), (1600003, (2, 256))])
+def test_launch_shape_chosen_by_batch_size_vs_oracle(n, shape):
+    """The library picks boards per lane and workgroup size from the batch size: every
+    region of that table, odd batch sizes, against the oracle."""
+    from qtttgym_amd import VecEnv, _native
+    assert _native.step_launch_shape(n) == shape
+    seed, off = 19, 5 * n
+    env = VecEnv(n, seed=seed, auto_reset=True, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    for t in range(7):
+        a = env.sample_actions()
+        a_or = ob.sample_actions(seed, t, off, True)
+        assert np.array_equal(_np(a), a_or), t
+        reward, term = env.step_raw(a)
+        r_or, t_or = ob.step(a_or, None, seed, t, off, True)
+        assert np.array_equal(_np(reward).view(np.uint32), r_or.view(np.uint32)), t
+        assert np.array_equal(_np(term).astype(np.uint8), t_or), t
+    _assert_same_as_oracle(env, ob, (n, shape))
 
 
 @pytest.mark.parametrize("n", [1001, 65536])

@@ -16,7 +16,7 @@ tools/sweep_boards.sh "$out/sweep.jsonl" > /dev/null 2> "$out/sweep.err"
 tools/sweep_boards.sh "$out/sweep_gym.jsonl" --mode gym > /dev/null 2>> "$out/sweep.err"
 python3 tools/bench_rows.py > "$out/rows.jsonl" 2> "$out/rows.err"
 python3 tools/facade_latency.py > "$out/facade.json" 2> "$out/facade.err"
-timeout -k 10 300 tools/stepbench 1048576 200 12 qtttgym_amd/libqttt_hip.so:2:0 gpurun_tmp/lib20/libqttt_hip.so:2:0 gpurun_tmp/libstamp/libqttt_hip.so:2:0 > "$out/stepbench.txt" 2>&1
-timeout -k 10 120 tools/stepbench 262144 400 8 qtttgym_amd/libqttt_hip.so:2:0 gpurun_tmp/lib20/libqttt_hip.so:2:0 > "$out/stepbench_262144.txt" 2>&1
+timeout -k 10 300 tools/stepbench 1048576 200 12 qtttgym_amd/libqttt_hip.so:0:0 gpurun_tmp/lib20/libqttt_hip.so:2:0 gpurun_tmp/libstamp/libqttt_hip.so:0:0 > "$out/stepbench.txt" 2>&1
+timeout -k 10 120 tools/stepbench 262144 400 8 qtttgym_amd/libqttt_hip.so:0:0 gpurun_tmp/lib20/libqttt_hip.so:2:0 > "$out/stepbench_262144.txt" 2>&1
 rocminfo > "$out/rocminfo.txt" 2>&1; nproc > "$out/nproc.txt"; grep -m1 "model name" /proc/cpuinfo >> "$out/nproc.txt"
 ls "$out"

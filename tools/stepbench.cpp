@@ -5,7 +5,7 @@
 // device differences cancel.  Also times a "traffic floor" kernel that moves the same bytes per
 // board with no game logic.
 //   hipcc --offload-arch=gfx950 -O3 -Iinclude tools/stepbench.cpp -ldl -o tools/stepbench
-//   tools/stepbench N K REPS  lib.so:bpl:pipe [lib.so:bpl:pipe ...]
+//   tools/stepbench N K REPS  lib.so[:boards_per_lane[:workgroup_size]] ...   (0 = the library's own choice)
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>
@@ -115,7 +115,7 @@ int main(int argc, char **argv) {
     std::vector<Lib> libs;
     for (int i = 4; i < argc; ++i) {
         Lib L; L.spec = argv[i];
-        char path[512]; int bpl = 2, pipe = 0;
+        char path[512]; int bpl = 0, pipe = 0;      // lib.so:boards_per_lane:workgroup_size, 0 = the library's choice
         if (sscanf(argv[i], "%511[^:]:%d:%d", path, &bpl, &pipe) < 1) return 2;
         L.path = path; L.bpl = bpl; L.pipe = pipe;
         L.h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -216,9 +216,14 @@ int main(int argc, char **argv) {
         int (*set_stamps)(void *) = nullptr;
         *(void **)(&set_stamps) = dlsym(L.h, "qttt_debug_set_stamps");
         if (set_stamps) {
-            int64_t n_waves = (n / L.bpl + 63) / 64;
+            int eff_bpl = L.bpl, eff_blk = 0;
+            int (*shape)(int64_t, int *, int *) = nullptr;
+            *(void **)(&shape) = dlsym(L.h, "qttt_step_launch_shape");
+            L.set_tuning(L.bpl, L.pipe);
+            if (shape) shape(n, &eff_bpl, &eff_blk);
+            if (!eff_bpl) eff_bpl = 2;
+            int64_t n_waves = (n / eff_bpl + 63) / 64;
             u64 *dbuf; CK(hipMalloc(&dbuf, n_waves * 32)); CK(hipMemset(dbuf, 0, n_waves * 32));
-            L.set_tuning(L.bpl, 0);
             L.reset(state, n, s);
             L.step_many(state, actions, nullptr, seed, 0, 0, 1, reward, term, 0, n, W + 5, s);
             CK(hipStreamSynchronize(s));
