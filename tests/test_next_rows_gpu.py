@@ -54,6 +54,19 @@ def test_node_info_and_encode_match_reference(gx):
     assert np.array_equal(_np(info["terminal"]), gx["p_terminal"])
     assert np.array_equal(_np(info["legal"]).view(np.uint64), mask_to_bits(gx["p_mask"]))
     assert np.array_equal(_np(info["key"]), gx["p_hash"])          # Python's hash(), bit for bit
+    # out= reuses the caller's buffers (no allocation per call)
+    for v in info.values():
+        v.zero_()
+    again = env.node_info(out=info)
+    assert again is info and np.array_equal(_np(info["key"]), gx["p_hash"])
+    assert np.array_equal(_np(info["winner"]), gx["p_winner"])
+    pair = env.check_win()
+    ref = (_np(pair[0]).copy(), _np(pair[1]).copy())
+    pair[0].zero_(); pair[1].zero_()
+    back = env.check_win(out=pair)
+    assert back[0] is pair[0] and np.array_equal(_np(pair[0]), ref[0]) and np.array_equal(_np(pair[1]), ref[1])
+    with pytest.raises(ValueError):
+        env.check_win(out=(pair[0][:-1], pair[1]))
     vec, mask = env.encode()
     # reference builds float64 (mcts.py:67-85); values are 0, 1, 1/3: exact after rounding to f32
     assert np.array_equal(_np(vec), gx["p_vector"].astype(np.float32))

@@ -83,12 +83,16 @@ def main():
     t = timed(lambda: env.check_win(), reps=10)
     p1, p2 = env.check_win()
     t_raw = timed(lambda: env._lib.qttt_check_win(env.state.data_ptr(), p1.data_ptr(), p2.data_ptr(), n, s), reps=20)
-    out.append({"row": "check_win", "boards": n, "us": t * 1e6, "us_kernel_only": t_raw * 1e6, "output_bytes_per_board": 2})
+    t_out = timed(lambda: env.check_win(out=(p1, p2)), reps=20)
+    out.append({"row": "check_win", "boards": n, "us": t * 1e6, "us_out_reuse": t_out * 1e6, "us_kernel_only": t_raw * 1e6,
+                "output_bytes_per_board": 2})
     t = timed(lambda: env.node_info(), reps=10)
     ni = env.node_info()
     t_raw = timed(lambda: env._lib.qttt_node_info(env.state.data_ptr(), ni["winner"].data_ptr(), ni["terminal"].data_ptr(),
                                                   ni["legal"].data_ptr(), ni["key"].data_ptr(), n, s), reps=20)
-    out.append({"row": "node_info", "boards": n, "us": t * 1e6, "us_kernel_only": t_raw * 1e6, "output_bytes_per_board": 18})
+    t_out = timed(lambda: env.node_info(out=ni), reps=20)
+    out.append({"row": "node_info", "boards": n, "us": t * 1e6, "us_out_reuse": t_out * 1e6, "us_kernel_only": t_raw * 1e6,
+                "output_bytes_per_board": 18})
     # fused replay (QTTT_FLAG_FUSED): T steps per launch, boards in registers
     for n in (4096, 262144, 1 << 20):
         T = 64
