@@ -12,10 +12,11 @@ namespace {
 
 // Env._observation (env.py:68-85) of stored boards: two boards per lane (one 16-byte load per
 // plane, as the step kernel) through the same LDS tiles and the same obs_board() as the fused step
-// kernel.  A workgroup owns 2 * QTTT_BLOCK consecutive boards; the last board of an odd batch is
+// kernel.  A workgroup owns 2 * BLOCK consecutive boards; the last board of an odd batch is
 // read with scalar loads.
-__global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
-    constexpr u32 TILE_BOARDS = QTTT_BLOCK * 2;
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
+    constexpr u32 TILE_BOARDS = BLOCK * 2;
     __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(TILE_BOARDS)];
     __shared__ __attribute__((aligned(16))) u32 olut[OBS_LUT_BYTES / 4];
     const u32 olw = threadIdx.x < OBS_LUT_BYTES / 4 ? (&g_obs_lut.sel[0][0])[threadIdx.x] : 0u;   // see step_kernel
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void observe_kernel(const u64 *pP, cons
         if (w0 < valid) obs_wave_copy_out<TILE_BOARDS>(otile, obs, base, w0, min(w0 + 128u, valid));
     } else {
         __syncthreads();
-        obs_copy_out<QTTT_BLOCK, TILE_BOARDS>(otile, obs, base, valid);
+        obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, base, valid);
     }
 }
 

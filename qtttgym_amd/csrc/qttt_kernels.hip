@@ -342,8 +342,16 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     if (((uintptr_t)q_p1 & 1u) || ((uintptr_t)q_p2 & 7u)) return QTTT_ERR_ACTION;   // 2- / 8-byte LDS row stores
     Planes p = planes(const_cast<void *>(state), n);
     const ObsOut o = {classical, q_p1, q_p1_len, q_p2, q_p2_len, turn};
-    hipLaunchKernelGGL(observe_kernel, dim3((unsigned)((n + 2 * QTTT_BLOCK - 1) / (2 * QTTT_BLOCK))), dim3(QTTT_BLOCK), 0,
-                       (hipStream_t)stream, p.P, p.Q, o, n);
+    // 256-thread workgroups: best or tied at every batch size for this write-heavy kernel (us per launch,
+    // 256 / 512 / 1024 threads: 65 536 boards 3.9 / 4.3 / 5.6, 262 144: 4.9 / 4.8 / 6.2, 1 M: 9.0 / 9.3 / 9.6,
+    // 4 M: 33.6 / 34.8 / 38.6)
+    const int blk = tuning_block() ? tuning_block() : 256;
+#define QTTT_OBSERVE(BLK) hipLaunchKernelGGL((observe_kernel<BLK>), dim3((unsigned)((n + 2 * (BLK) - 1) / (2 * (BLK)))), \
+                                             dim3(BLK), 0, (hipStream_t)stream, p.P, p.Q, o, n)
+    if (blk == 1024) QTTT_OBSERVE(1024);
+    else if (blk == 256) QTTT_OBSERVE(256);
+    else QTTT_OBSERVE(QTTT_BLOCK);
+#undef QTTT_OBSERVE
     return launch_status();
 }
 
