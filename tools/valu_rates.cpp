@@ -83,6 +83,8 @@ KERNEL(k_fadd, "v_add_f32 %0, %1, %0\n v_mul_f32 %2, %3, %2\n")
 KERNEL(k_ldexp, "v_ldexp_f32 %0, %1, %0\n v_ldexp_f32 %2, %3, %2\n")
 KERNEL(k_frexp, "v_frexp_exp_i32_f32 %0, %1\n v_frexp_exp_i32_f32 %2, %3\n")
 KERNEL(k_sad, "v_sad_u32 %0, %1, %2, %0\n v_sad_u32 %2, %3, %1, %2\n")
+KERNEL(k_mad_u64, "v_mad_u64_u32 %4, vcc, %1, %3, %4\n v_mad_u64_u32 %5, vcc, %3, %1, %5\n")
+KERNEL(k_mul_hi, "v_mul_hi_u32 %0, %1, %0\n v_mul_hi_u32 %2, %3, %2\n")
 KERNEL(k_xor3x, "v_xor_b32 %0, %1, %0\n v_and_b32 %2, %3, %2\n v_or_b32 %1, %0, %1\n")
 
 template <typename F>
@@ -116,6 +118,6 @@ int main() {
     T(k_min_max) T(k_add3) T(k_dep_xor) T(k_pk_mixed)
     T(k_and) T(k_or) T(k_add) T(k_sub) T(k_shl_c) T(k_shr_c) T(k_bfi) T(k_or3) T(k_not) T(k_and_lit)
     T(k_cndmask_s) T(k_cmp_e32) T(k_lshl_add) T(k_add_lshl) T(k_xor_dpp) T(k_fma) T(k_pk_add) T(k_pk_lshl) T(k_xnor) T(k_xor4) T(k_mix_xor_shl)
-    T(k_shr_v) T(k_ashr_v) T(k_shr64_c) T(k_addco) T(k_subrev) T(k_and_s) T(k_bitop3_s) T(k_bitop3_c) T(k_mov_s) T(k_max_i) T(k_cvt) T(k_fadd) T(k_ldexp) T(k_frexp) T(k_sad) T(k_xor3x)
+    T(k_shr_v) T(k_ashr_v) T(k_shr64_c) T(k_addco) T(k_subrev) T(k_and_s) T(k_bitop3_s) T(k_bitop3_c) T(k_mov_s) T(k_max_i) T(k_cvt) T(k_fadd) T(k_ldexp) T(k_frexp) T(k_sad) T(k_xor3x) T(k_mad_u64) T(k_mul_hi)
     return 0;
 }
