@@ -15,9 +15,10 @@ namespace {
 // `actions` when that is not null) — qttt_sample_actions + qttt_step in one launch.
 // OBS: Env.step returns the observation too (env.py:46,53): it is written from the registers the
 // step already holds, through the LDS tiles above — qttt_step + qttt_observe in one launch.
-// BLOCK: workgroup size, chosen by the host per launch: 1024 for batches that fill the chip with
-// 1024-thread workgroups (7.2-7.5 us instead of 7.6-7.7 per 1 M boards), QTTT_BLOCK = 512 below
-// (262 144 boards: 3.8 us with 512 against 4.9 with 1024, which would leave half the CUs idle).
+// BLOCK, BPL: workgroup size and boards per lane, chosen by the host per launch from the batch size
+// (auto_tuning() in qttt_kernels.hip holds the measured table: one board per lane in 256-thread
+// workgroups below ~450 K boards, 1024-thread workgroups where they fill the chip exactly once,
+// two boards per lane in 256-thread workgroups from 2 M boards up).
 template <int BLOCK, int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, uint16_t *__restrict__ actions,
