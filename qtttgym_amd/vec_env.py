@@ -35,6 +35,8 @@ class VecEnv:
                 "CPU path" % (device,))
         if not torch.cuda.is_available():
             raise _native.QtttNativeError("no HIP device visible (torch.cuda.is_available() is False)")
+        if self.device.index is None:                     # pin "cuda" to the device that is current now
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._lib = _native.lib()
         self.seed = int(seed)
         self.auto_reset = bool(auto_reset)
