@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Randomised soak of the step path against the oracle, beyond what the test suite pins: random batch
+sizes (odd, around the launch-shape thresholds), board offsets (incl. across 2^32), launch shapes,
+explicit / hashed collapse bits, auto-reset on / off, adversarial actions (out of range, same square,
+classical squares), the fused step + observation kernel, export and check_win.  Prints one line per
+case; exits non-zero on the first mismatch.     python3 tools/soak_parity.py [cases] [seed]
+(Test infrastructure: it imports oracle/, like tests/.)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import oracle  # noqa: E402
+from qtttgym_amd import VecEnv, _native  # noqa: E402
+
+
+def npy(t):
+    return t.cpu().numpy()
+
+
+def one_case(rng, k):
+    L = _native.lib()
+    sizes = [1, 2, 3, 63, 64, 65, 127, 129, 511, 1000, 4097, 65535, 262143, 458751, 458753, 524289, 917503, 917505,
+             1048577, 1572865, 2097153]
+    n = int(rng.choice(sizes)) if rng.random() < 0.7 else int(rng.integers(1, 300000))
+    off = int(rng.choice([0, 7, 2**32 - n // 2 - 1, 2**33 + 12345, int(rng.integers(0, 2**40))]))
+    shape = [(0, 0), (1, 256), (2, 256), (1, 512), (2, 512), (4, 512), (1, 1024), (2, 1024)][int(rng.integers(0, 8))]
+    auto_reset = bool(rng.integers(0, 2))
+    use_bits = bool(rng.integers(0, 2))
+    adversarial = rng.random() < 0.4
+    observe = bool(rng.integers(0, 2))
+    seed = int(rng.integers(0, 2**62))
+    steps = int(rng.integers(3, 14)) if n < 600000 else int(rng.integers(3, 7))
+    assert L.qttt_set_tuning(*shape) == 0
+    env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    for t in range(steps):
+        a_or = ob.sample_actions(seed, t, off, auto_reset)
+        a = env.sample_actions()
+        assert np.array_equal(npy(a), a_or), ("policy", t)
+        if adversarial:                                   # overwrite a random third of the actions with junk
+            junk = rng.integers(0, 12, size=(n, 2)).astype(np.uint8)
+            junk[rng.random(n) < 0.1] = 255
+            sel = rng.random(n) < 0.33
+            a_or = np.where(sel[:, None], junk, a_or).astype(np.uint8)
+            a = torch.from_numpy(a_or).to(env.device)
+        bits_np = rng.integers(0, 2, size=n).astype(np.uint8) if use_bits else None
+        bits = torch.from_numpy(bits_np).to(env.device) if use_bits else None
+        if observe:
+            o, reward, term = env.step_observe_raw(a, bits)
+        else:
+            reward, term = env.step_raw(a, bits)
+        r_or, t_or = ob.step(a_or, bits_np, seed, t, off, auto_reset)
+        assert np.array_equal(npy(reward).view(np.uint32), r_or.view(np.uint32)), ("reward", t)
+        assert np.array_equal(npy(term).astype(np.uint8), t_or), ("terminated", t)
+        if observe:
+            classical, q1, l1, q2, l2, turn = ob.observe()
+            for name, ref in (("classical", classical), ("q_states_p1", q1), ("q_states_p1_len", l1),
+                              ("q_states_p2", q2), ("q_states_p2_len", l2), ("turn", turn)):
+                assert np.array_equal(npy(o[name]), ref), (name, t)
+    ex = {kk: npy(v) for kk, v in env.export_boards().items()}
+    assert np.array_equal(ex["board"], ob.board) and np.array_equal(ex["moves"], ob.moves)
+    assert np.array_equal(ex["n_moves"], ob.n_moves) and np.array_equal(ex["qmask"].view(np.uint16), ob.qmask)
+    p1, p2 = env.check_win()
+    w1, w2 = ob.check_win()
+    assert np.array_equal(npy(p1), w1) and np.array_equal(npy(p2), w2)
+    return dict(case=k, n=n, offset=off, shape=shape, auto_reset=auto_reset, bits=use_bits, adversarial=adversarial,
+                observe=observe, steps=steps)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t0 = time.time()
+    for k in range(cases):
+        info = one_case(rng, k)
+        print("ok", info, "%.0f s" % (time.time() - t0), flush=True)
+    _native.lib().qttt_set_tuning(0, 0)
+    print("soak ok: %d cases" % cases)
+
+
+if __name__ == "__main__":
+    main()
