@@ -124,6 +124,32 @@ def test_expand_65536_boards_vs_oracle():
     assert r.shape == (n,)
 
 
+def test_node_info_and_encode_at_every_depth_vs_oracle():
+    """node_info (winner, terminal, legal mask, CPython hash key) and encode on boards frozen at every
+    depth 0..9 — finished games included: nine real moves, eight moves + the autofill, early wins."""
+    from qtttgym_amd import VecEnv
+    n, seed = 20000, 29
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    rng = np.random.default_rng(4)
+    depth = rng.integers(0, 10, n)
+    for t in range(9):
+        a = _np(env.sample_actions())
+        a[depth <= t] = 255                                   # frozen boards get a noop
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t)
+    nm = ob.n_moves
+    assert (nm == 9).sum() > 1000 and (nm == 0).sum() > 500
+    winner, terminal, legal, key = oracle.node_info(ob)
+    info = env.node_info()
+    assert np.array_equal(_np(info["winner"]), winner)
+    assert np.array_equal(_np(info["terminal"]).astype(np.uint8), terminal)
+    assert np.array_equal(_np(info["legal"]).view(np.uint64), legal)
+    assert np.array_equal(_np(info["key"]), key)
+    vec, _ = env.encode()
+    assert np.array_equal(_np(vec), oracle.to_vector(ob).astype(np.float32))
+
+
 def test_rollout_equals_stepping_to_the_end():
     from qtttgym_amd import VecEnv
     n, seed = 8192, 23
