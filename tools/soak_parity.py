@@ -3,7 +3,8 @@
 sizes (odd, around the launch-shape thresholds), board offsets (incl. across 2^32), launch shapes,
 explicit / hashed collapse bits, auto-reset on / off, adversarial actions (out of range, same square,
 classical squares), the fused step + observation kernel, export and check_win.  Prints one line per
-case; exits non-zero on the first mismatch.     python3 tools/soak_parity.py [cases] [seed]
+case; exits non-zero on the first mismatch.     python3 tools/soak_parity.py [cases] [seed] [rows]
+(`rows`: the SURVEY §8(f) rows instead — node_info, expand, rollout, encode on boards frozen at random depths.)
 (Test infrastructure: it imports oracle/, like tests/.)"""
 import os
 import sys
@@ -72,12 +73,54 @@ def one_case(rng, k):
                 observe=observe, steps=steps)
 
 
+def rows_case(rng, k):
+    """SURVEY §8(f) rows on boards frozen at random depths: node_info, expand, rollout, encode."""
+    n = int(rng.choice([1, 2, 63, 65, 255, 257, 511, 513, 1000, 4099, 20001]))
+    off = int(rng.choice([0, 5, 2**32 - n // 2 - 1, int(rng.integers(0, 2**40))]))
+    seed = int(rng.integers(0, 2**62))
+    env = VecEnv(n, seed=seed, board_offset=off)
+    ob = oracle.OracleBoards(n)
+    depth = rng.integers(0, 10, n)
+    for t in range(9):
+        a = npy(env.sample_actions())
+        a[depth <= t] = 255
+        env.step_raw(torch.from_numpy(a).to(env.device))
+        ob.step(a, None, seed, t, off)
+    winner, terminal, legal, key = oracle.node_info(ob)
+    info = env.node_info()
+    assert np.array_equal(npy(info["winner"]), winner) and np.array_equal(npy(info["terminal"]).astype(np.uint8), terminal)
+    assert np.array_equal(npy(info["legal"]).view(np.uint64), legal) and np.array_equal(npy(info["key"]), key)
+    vec, mask = env.encode()
+    assert np.array_equal(npy(vec), oracle.to_vector(ob).astype(np.float32))
+    assert np.array_equal(npy(mask), (legal[:, None] >> np.arange(36, dtype=np.uint64)[None, :] & np.uint64(1)).astype(bool))
+    act = rng.integers(0, 40, n).astype(np.uint8)           # 36..39: not an action -> no children
+    out = env.expand(torch.from_numpy(act))
+    nch, kids, w2, t2, l2, k2 = oracle.expand(ob, act)
+    assert np.array_equal(npy(out["n_children"]), nch)
+    for c, child in enumerate((out["child0"], out["child1"])):
+        sel = nch > c
+        ex = {kk: npy(v) for kk, v in child.export_boards().items()}
+        assert np.array_equal(ex["board"][sel], kids[c].board[sel]) and np.array_equal(ex["moves"][sel], kids[c].moves[sel])
+        assert np.array_equal(ex["qmask"].view(np.uint16)[sel], kids[c].qmask[sel])
+        assert np.array_equal(npy(out["winner"])[sel, c], w2[sel, c]) and np.array_equal(npy(out["key"])[sel, c], k2[sel, c])
+        assert np.array_equal(npy(out["legal"]).view(np.uint64)[sel, c], l2[sel, c])
+        assert np.array_equal(npy(out["terminal"])[sel, c].astype(np.uint8), t2[sel, c])
+    s0 = int(rng.integers(0, 1000))
+    result, plies, final = env.rollout(step_idx0=s0, return_final=True)
+    res_o, plies_o, fin_o = oracle.rollout(ob, seed, s0, off)
+    assert np.array_equal(npy(result), res_o) and np.array_equal(npy(plies), plies_o)
+    exf = {kk: npy(v) for kk, v in final.export_boards().items()}
+    assert np.array_equal(exf["board"], fin_o.board) and np.array_equal(exf["moves"], fin_o.moves)
+    return dict(case=k, rows=True, n=n, offset=off)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    rows = len(sys.argv) > 3 and sys.argv[3] == "rows"
     t0 = time.time()
     for k in range(cases):
-        info = one_case(rng, k)
+        info = rows_case(rng, k) if rows else one_case(rng, k)
         print("ok", info, "%.0f s" % (time.time() - t0), flush=True)
     _native.lib().qttt_set_tuning(0, 0)
     print("soak ok: %d cases" % cases)
