@@ -48,16 +48,32 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const u64 *pP, const u64
     }
 }
 
+// Board.check_win (board.py:71-115) of stored boards: two boards per lane (one 16-byte load of plane
+// P, one 2-byte store per output), the line table in LDS.
 __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
     const u64 *pP, const u64 *pQ, int8_t *p1_round, int8_t *p2_round, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     (void)pQ;
-    const Lite s = lite_unpack(load_stream(&pP[i]));
-    int p1, p2;
-    fast_check_win(s, p1, p2);
-    p1_round[i] = (int8_t)p1;
-    p2_round[i] = (int8_t)p2;
+    const int64_t j = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;   // boards 2j, 2j+1
+    const int64_t i0 = 2 * j;
+    typedef Vec<u64, 2> V64;
+    V64 p;
+    p.v[0] = p.v[1] = 0ull;
+    if (i0 + 1 < n) p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]);    // requested before the table fill
+    else if (i0 < n) p.v[0] = pP[i0];
+    fill_line_lut<QTTT_COLD_BLOCK>(lut);                  // ends with the workgroup barrier
+    if (i0 >= n) return;
+    int a1, a2, b1, b2;
+    fast_check_win(lite_unpack(p.v[0]), lut, a1, a2);
+    fast_check_win(lite_unpack(p.v[1]), lut, b1, b2);
+    if (i0 + 1 < n && ((reinterpret_cast<uintptr_t>(p1_round) | reinterpret_cast<uintptr_t>(p2_round)) & 1u) == 0u) {
+        reinterpret_cast<uint16_t *>(p1_round)[j] = (uint16_t)((u32)(a1 & 0xFF) | ((u32)(b1 & 0xFF) << 8));
+        reinterpret_cast<uint16_t *>(p2_round)[j] = (uint16_t)((u32)(a2 & 0xFF) | ((u32)(b2 & 0xFF) << 8));
+    } else {
+        p1_round[i0] = (int8_t)a1;
+        p2_round[i0] = (int8_t)a2;
+        if (i0 + 1 < n) { p1_round[i0 + 1] = (int8_t)b1; p2_round[i0 + 1] = (int8_t)b2; }
+    }
 }
 
 // Board.moves / .board / .qstructs (board.py:4-6) as arrays, straight from the packed words: the

@@ -154,7 +154,7 @@ __device__ __forceinline__ Lite lite_unpack(u64 P) {
 // a line (three X marks need rounds 0,2,4 at least); likewise p2_round over {5,7}.  "round <= m" is
 // "code >= 15-m" on the complemented nibbles, tested for eight squares at once (classical codes are
 // 7..15: bit 3 set and low three bits >= T-8 <=> adding 16-T carries into bit 3).
-__device__ __forceinline__ void fast_check_win(const Lite &s, int &p1, int &p2) {
+__device__ __forceinline__ void fast_check_win(const Lite &s, const uint8_t *lds_lut, int &p1, int &p2) {
     const u32 W = (u32)(s.P >> 2);                                   // codes of squares 0..7
     const u32 c8 = (u32)(s.P >> 34) & 0xFu;
     const u32 par = W & 0x11111111u;                                 // odd code = even round = X
@@ -169,9 +169,11 @@ __device__ __forceinline__ void fast_check_win(const Lite &s, int &p1, int &p2) 
         ge[k] = ((__builtin_amdgcn_udot8(y, 0x00008421u, 0u, false) |
                   (__builtin_amdgcn_udot8(y, 0x84210000u, 0u, false) << 4)) >> 3) | ((c8 >= T ? 1u : 0u) << 8);
     }
-    const uint8_t *lut = g_line_lut.b;
-    p1 = lut[X & ge[2]] ? 4 : (lut[X & ge[0]] ? 6 : (lut[X] ? 8 : -1));
-    p2 = lut[O & ge[1]] ? 5 : (lut[O] ? 7 : -1);
+    // five reads of the workgroup's LDS line table (a dword per mask), all issued up front
+    const u32 *l32 = reinterpret_cast<const u32 *>(lds_lut);
+    const u32 x4 = l32[X & ge[2]], x6 = l32[X & ge[0]], x8 = l32[X], o5 = l32[O & ge[1]], o7 = l32[O];
+    p1 = x4 ? 4 : (x6 ? 6 : (x8 ? 8 : -1));
+    p2 = o5 ? 5 : (o7 ? 7 : -1);
 }
 
 // GameState.update_winner (mcts.py:52-65): winner 1 True / 0 False / -1 None; terminal = a line or

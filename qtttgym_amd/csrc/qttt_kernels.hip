@@ -360,7 +360,7 @@ int qttt_check_win(const void *state, int8_t *p1_round, int8_t *p2_round, int64_
     if (n == 0) return 0;
     if (!state || !p1_round || !p2_round) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(check_win_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(check_win_kernel, dim3(cold_grid_for((n + 1) / 2)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
                        p.P, p.Q, p1_round, p2_round, n);
     return launch_status();
 }

@@ -89,23 +89,10 @@ __device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/ste
 #endif
 
 // ------------------------------------------------------------------ 3-in-a-row lookup table
-// line_lut[m] = 0x7F iff the 9-bit square mask m contains one of the 8 lines of board.py:85-110.
-// The LDS copy keeps one entry per DWORD (LINE_LUT_BYTES = 2 KB), because every mask of the hot
-// path lives "times four" (the nibbles sit at bit 4v+2): the byte offset into the table is the
-// mask itself, no shift.
-__host__ __device__ constexpr bool mask_has_line(u32 m) {
-    return (m & 0x007u) == 0x007u || (m & 0x038u) == 0x038u || (m & 0x1C0u) == 0x1C0u ||
-           (m & 0x049u) == 0x049u || (m & 0x092u) == 0x092u || (m & 0x124u) == 0x124u ||
-           (m & 0x054u) == 0x054u || (m & 0x111u) == 0x111u;
-}
-
-struct LineLut {
-    uint8_t b[512];
-    constexpr LineLut() : b() {
-        for (u32 m = 0; m < 512; ++m) b[m] = mask_has_line(m) ? 0x7F : 0;   // 0x7F << 23 = 1.0f
-    }
-};
-__constant__ LineLut g_line_lut = LineLut();
+// Line table: entry m = 0x7F iff the 9-bit square mask m contains one of the 8 lines of
+// board.py:85-110 (0x7F << 23 = 1.0f), one entry per DWORD (LINE_LUT_BYTES = 2 KB) in LDS, because
+// every mask of the hot path lives "times four" (the nibbles sit at bit 4v+2): the byte offset into
+// the table is the mask itself, no shift.
 constexpr u32 LINE_LUT_BYTES = 2048;
 
 // The LDS copy is COMPUTED (thread w makes entry w, a dozen instructions once per launch), not

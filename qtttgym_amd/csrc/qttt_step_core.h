@@ -6,9 +6,9 @@
 namespace {
 
 // ====================================================================== the hot path
-// One Env.step (env.py:34-53) on the board held in (P0,P1,Q0,Q1).  `lut` is the LDS copy of
-// g_line_lut (one entry per dword).  Returns 0x7F iff a completed line exists afterwards (else 0);
-// P1's done bit is updated.
+// One Env.step (env.py:34-53) on the board held in (P0,P1,Q0,Q1).  `lut` is the workgroup's LDS
+// line table (fill_line_lut: one entry per dword, 0x7F = the mask holds a line).  Returns 0x7F iff a
+// completed line exists afterwards (else 0); P1's done bit is updated.
 template <bool AUTO_RESET>
 __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 act, u32 bit,
                                          const uint8_t *lut) {
