@@ -54,6 +54,29 @@ def test_env_record_call_validates_before_touching_the_device():
     assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, _native.ENV_STEP_RANDOM, None) == -2
 
 
+def test_launch_shape_table_and_overrides():
+    """qttt_step_launch_shape / qttt_set_tuning are host logic (no device work): the by-batch-size table
+    of DESIGN.md §2 and its overrides."""
+    from qtttgym_amd import _native
+    L = _native.lib()
+    try:
+        assert L.qttt_set_tuning(0, 0) == 0
+        expect = {1: (1, 256), 4096: (1, 256), 262144: (1, 256), 458752: (1, 256), 458753: (1, 1024),
+                  524288: (1, 1024), 524289: (2, 512), 917503: (2, 512), 917504: (2, 1024), 1048576: (2, 1024),
+                  1572864: (2, 1024), 1572865: (2, 256), 2097152: (2, 256), 1 << 25: (2, 256)}
+        for n, shape in expect.items():
+            assert _native.step_launch_shape(n) == shape, n
+        assert L.qttt_set_tuning(4, 1024) == 0 and _native.step_launch_shape(1 << 20) == (4, 512)   # 4 per lane: 512 only
+        assert L.qttt_set_tuning(2, 0) == 0 and _native.step_launch_shape(1 << 20) == (2, 512)
+        assert L.qttt_set_tuning(0, 256) == 0 and _native.step_launch_shape(1 << 20) == (2, 256)
+        for bad in ((3, 0), (8, 0), (-1, 0), (2, 128), (2, 2048), (0, -256)):
+            assert L.qttt_set_tuning(*bad) == -2
+        with pytest.raises(RuntimeError):
+            _native.step_launch_shape(-1)
+    finally:
+        assert L.qttt_set_tuning(0, 0) == 0
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "qtttgym_amd")
     for dirpath, _, files in os.walk(pkg):
