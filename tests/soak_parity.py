@@ -3,9 +3,9 @@
 sizes (odd, around the launch-shape thresholds), board offsets (incl. across 2^32), launch shapes,
 explicit / hashed collapse bits, auto-reset on / off, adversarial actions (out of range, same square,
 classical squares), the fused step + observation kernel, export and check_win.  Prints one line per
-case; exits non-zero on the first mismatch.     python3 tools/soak_parity.py [cases] [seed] [rows]
+case; exits non-zero on the first mismatch.     python3 tests/soak_parity.py [cases] [seed] [rows]
 (`rows`: the SURVEY §8(f) rows instead — node_info, expand, rollout, encode on boards frozen at random depths.)
-(Test infrastructure: it imports oracle/, like tests/.)"""
+(Test infrastructure, kept under tests/: it checks against oracle/ like the suite does; not collected by pytest.)"""
 import os
 import sys
 import time
