@@ -186,8 +186,11 @@ class VecEnv:
         """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info) from ONE kernel
         launch (the step kernel writes the observation from the registers it holds).  The returned
         tensors are the environment's own buffers, overwritten by the next step()/observ()."""
-        actions = self._as_actions(actions)
-        if bits is not None:
+        if not (torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == self.state.device
+                and actions.shape == (self.num_envs, 2)):         # (step_observe_raw checks the layout)
+            actions = self._as_actions(actions)
+        if bits is not None and not (torch.is_tensor(bits) and bits.dtype == torch.uint8
+                                     and bits.device == self.state.device):
             bits = torch.as_tensor(bits).to(torch.uint8).to(self.device).contiguous()
         obs, reward, terminated = self.step_observe_raw(actions, bits)
         return obs, reward, terminated, self._truncated, {}
