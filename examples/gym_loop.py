@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""The reference's gym loop (`obs, r, terminated, truncated, info = env.step(action)`, env.py:34-53)
+for N boards at once: a policy that reads the observation tensors on the GPU and answers with an
+action per board, auto-reset on, episode statistics accumulated on the device.
+
+    python examples/gym_loop.py [--boards 262144] [--steps 200]
+
+The policy here: play the uniform-legal random move, except take the centre square (4) together
+with the first other empty square whenever the centre is still empty — just enough to show a
+policy that depends on `obs["classical"]`.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qtttgym_amd import VecEnv  # noqa: E402
+
+
+def policy(env, obs):
+    a = env.sample_actions()                                   # uniform over legal pairs, u8[N, 2]
+    classical = obs["classical"]                               # i8[N, 9], -1 = not classical yet
+    empty = classical < 0
+    centre_free = empty[:, 4]
+    others = empty.clone()
+    others[:, 4] = False
+    first_other = others.to(torch.uint8).argmax(dim=1).to(torch.uint8)
+    use = centre_free & others.any(dim=1)
+    four = torch.full_like(first_other, 4)
+    return torch.stack((torch.where(use, four, a[:, 0]), torch.where(use, first_other, a[:, 1])), dim=1)   # no host sync
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--boards", type=int, default=262144)
+    ap.add_argument("--steps", type=int, default=200)
+    args = ap.parse_args()
+    env = VecEnv(args.boards, seed=1, auto_reset=True)
+    obs, _ = env.reset()
+    episodes = torch.zeros((), dtype=torch.int64, device=env.device)
+    lines = torch.zeros((), dtype=torch.int64, device=env.device)
+    for _ in range(10):                                         # warm the allocator and the kernels
+        obs, *_ = env.step(policy(env, obs))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obs, reward, terminated, truncated, info = env.step(policy(env, obs))
+        episodes += terminated.sum()
+        lines += (reward != 0).sum()                           # env.py:49: -1.0 iff somebody holds a line
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%d boards x %d steps in %.3f s = %.3g env steps/s (policy included); %d episodes finished, %d with a line"
+          % (args.boards, args.steps, dt, args.boards * args.steps / dt, int(episodes), int(lines)))
+
+
+if __name__ == "__main__":
+    main()
