@@ -96,9 +96,21 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     int8_t *result, uint8_t *plies, u64 *fP, u64 *fQ, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    // nth9[m * 9 + r] = the r-th empty square of the 9-bit mask m: nine plies of policy per board make a
+    // full table (4.5 KB, computed here: thread m writes row m) cheaper than the two-level lookup of
+    // policy_nth()
+    __shared__ uint8_t nth9[512 * 9];
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
     fill_policy_lut<QTTT_BLOCK>(plut);
+    for (u32 m = threadIdx.x; m < 512u; m += QTTT_BLOCK) {
+        u32 r = 0;
+#pragma unroll
+        for (u32 v = 0; v < 9; ++v) {
+            nth9[m * 9u + r] = (uint8_t)v;                 // kept only if bit v is set (r advances), else overwritten
+            r += m >> v & 1u;                              // r <= v inside the loop: the store stays in row m
+        }
+    }
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
@@ -110,7 +122,11 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
         const u64 key = launch_key(seed, step_idx0 + p);
         const u32 h1 = lowbias32(id ^ (u32)key);
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
-        step_core<false>(P0, P1, Q0, Q1, policy_action(plut, empty, h2), h1 >> 31, lut);
+        // policy_action() with the full table: the k-th legal pair (i < j) -> squares (a < b)
+        const u32 e = (u32)__builtin_popcount(empty);
+        const u32 ij = plut[e * 36u + __umulhi(h2, (e * (e - 1u)) >> 1)];
+        const u32 act = (u32)nth9[empty * 9u + (ij & 0xFu)] | ((u32)nth9[empty * 9u + (ij >> 4)] << 8);
+        step_core<false, true>(P0, P1, Q0, Q1, act, h1 >> 31, lut);   // legal and sorted
         played += 1u;
     }
     const u64 oP = (u64)P0 | ((u64)P1 << 32), oQ = (u64)Q0 | ((u64)Q1 << 32);

@@ -9,7 +9,9 @@ namespace {
 // One Env.step (env.py:34-53) on the board held in (P0,P1,Q0,Q1).  `lut` is the workgroup's LDS
 // line table (fill_line_lut: one entry per dword, 0x7F = the mask holds a line).  Returns 0x7F iff a
 // completed line exists afterwards (else 0); P1's done bit is updated.
-template <bool AUTO_RESET>
+// TRUSTED: the caller guarantees a legal action with action[0] < action[1] (the in-kernel policy of the
+// rollout does): no sorting, no validation.
+template <bool AUTO_RESET, bool TRUSTED = false>
 __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 act, u32 bit,
                                          const uint8_t *lut) {
     if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
@@ -20,11 +22,11 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
         Q1 &= keep;
     }
     const u32 a = act & 0xFFu, b = act >> 8;            // action[0], action[1] (env.py:37-38)
-    const u32 lo = min(a, b), hi = max(a, b);           // board.py:16-18
+    const u32 lo = TRUSTED ? a : min(a, b), hi = TRUSTED ? b : max(a, b);   // board.py:16-18
     // the two squares as a mask at the classical mask's place in P1 (only looked at when hi < 9)
     const u32 pmS = ((1u << P1_CL_SHIFT) << (lo & 31u)) | ((1u << P1_CL_SHIFT) << (hi & 31u));
     // board.py:10-15 (+ IndexError for >8, swallowed at env.py:41): reject before mutating
-    if (hi < 9u && lo != hi && (P1 & pmS) == 0u) {
+    if (TRUSTED || (hi < 9u && lo != hi && (P1 & pmS) == 0u)) {
         const u32 pm = pmS >> P1_CL_SHIFT;
         const u32 n4 = (P1 >> (P1_N_SHIFT - 2u)) & 0x3Cu;            // 4 * moves played (bits 6,7 of P1 are 0)
         u64 comps = (u64)Q1 | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
