@@ -54,6 +54,28 @@ def test_env_record_call_validates_before_touching_the_device():
     assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, _native.ENV_STEP_RANDOM, None) == -2
 
 
+def test_header_is_plain_c_and_the_env_record_layout_matches_the_binding(tmp_path):
+    """include/qttt.h must stay a C header (the reference side would bind it through ctypes / cffi / cgo):
+    gcc -std=c99 -pedantic compiles it, and sizeof / offsetof of struct qttt_env as a C compiler sees them are
+    the ones of the ctypes mirror in qtttgym_amd/_native.py."""
+    import ctypes
+    import subprocess
+    from qtttgym_amd import _native
+    src = tmp_path / "probe.c"
+    fields = [f[0] for f in _native.EnvRecord._fields_]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "qttt.h"\nint main(void) {\n'
+                   '  printf("%zu", sizeof(qttt_env));\n'
+                   + "".join('  printf(" %%zu", offsetof(qttt_env, %s));\n' % f for f in fields)
+                   + '  printf(" %d %d", QTTT_ABI_VERSION, QTTT_BOARD_RECORD_BYTES);\n  return 0;\n}\n')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_native.EnvRecord)
+    assert out[1:1 + len(fields)] == [getattr(_native.EnvRecord, f).offset for f in fields]
+    assert out[-2] == _native.ABI_VERSION and out[-1] == _native.BOARD_RECORD_BYTES
+
+
 def test_launch_shape_table_and_overrides():
     """qttt_step_launch_shape / qttt_set_tuning are host logic (no device work): the by-batch-size table
     of DESIGN.md §2 and its overrides."""
