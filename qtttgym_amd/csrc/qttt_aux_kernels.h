@@ -240,25 +240,42 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void board_op_kernel(const uint8_t
     (void)win;
 }
 
-// legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343)
+// legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343).  Two boards
+// per lane: one 16-byte load of plane P, one 4-byte store of the two actions.
+__device__ __forceinline__ u32 sampled_action(const uint8_t *plut, u64 Pw, u64 board_id, u32 key_lo, u32 key_hi,
+                                              u32 auto_reset) {
+    const u32 P1 = (u32)(Pw >> 32);
+    const u32 cl = (auto_reset && (P1 >> 31)) ? 0u : (P1 >> P1_CL_SHIFT) & 0x1FFu;
+    const u32 empty = ~cl & 0x1FFu;
+    const u32 h1 = lowbias32(fold_id(board_id) ^ key_lo);
+    const u32 h2 = lowbias32(h1 ^ key_hi);
+    // fewer than two empty squares: rank_pair gives (0,0) and nth_bit[..][0] twice -> a == b, a noop;
+    // the spec (DESIGN.md §5) says (0,0)
+    return (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
+}
+
 __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     const u64 *pP, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint16_t *actions,
     int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
-    const u64 Pw = i < n ? load_stream(&pP[i]) : 0ull;      // requested before the table: the latencies overlap
+    const int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;   // boards 2j, 2j+1
+    const int64_t i0 = 2 * j;
+    typedef Vec<u64, 2> V64;
+    V64 p;
+    p.v[0] = p.v[1] = 0ull;
+    if (i0 + 1 < n) p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]);   // requested before the table: the latencies overlap
+    else if (i0 < n) p.v[0] = pP[i0];
     fill_policy_lut<QTTT_BLOCK>(plut);
     __syncthreads();
-    if (i >= n) return;
-    const u32 P1 = (u32)(Pw >> 32);
-    const u32 cl = (auto_reset && (P1 >> 31)) ? 0u : (P1 >> P1_CL_SHIFT) & 0x1FFu;
-    const u32 empty = ~cl & 0x1FFu;
-    const u32 h1 = lowbias32(fold_id(board_offset + (u64)i) ^ key_lo);
-    const u32 h2 = lowbias32(h1 ^ key_hi);
-    // fewer than two empty squares: rank_pair gives (0,0) and nth_bit[..][0] twice -> a == b, a noop;
-    // the spec (DESIGN.md §5) says (0,0)
-    const u32 act = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
-    actions[i] = (uint16_t)act;
+    if (i0 >= n) return;
+    const u32 a0 = sampled_action(plut, p.v[0], board_offset + (u64)i0, key_lo, key_hi, auto_reset);
+    if (i0 + 1 < n) {
+        const u32 a1 = sampled_action(plut, p.v[1], board_offset + (u64)i0 + 1u, key_lo, key_hi, auto_reset);
+        if ((reinterpret_cast<uintptr_t>(actions) & 3u) == 0u) reinterpret_cast<u32 *>(actions)[j] = a0 | (a1 << 16);
+        else { actions[i0] = (uint16_t)a0; actions[i0 + 1] = (uint16_t)a1; }
+    } else {
+        actions[i0] = (uint16_t)a0;
+    }
 }
 
 }  // namespace

@@ -411,7 +411,7 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // written as u16 pairs
     Planes p = planes(const_cast<void *>(state), n);
     const u64 key = launch_key(seed, step_idx);
-    hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0,
+    hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for((n + 1) / 2)), dim3(QTTT_BLOCK), 0,
                        (hipStream_t)stream, p.P, (u32)key, (u32)(key >> 32), (u64)board_offset,
                        (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), reinterpret_cast<uint16_t *>(actions), n);
     return launch_status();
