@@ -1,5 +1,10 @@
 #!/bin/bash
 # Every number DESIGN.md §6 quotes, in one go on the GPU box:  tools/round_numbers.sh gpurun_out/r02_final
+# The stepbench A/B lines want two extra builds under gpurun_tmp/ (git-ignored, they travel with gpurun):
+#   gpurun_tmp/lib20/libqttt_hip.so     round 1's 20-byte-state kernel:  git show 637ea87:qtttgym_amd/csrc/qttt_kernels.hip > /tmp/r1.hip
+#                                       && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -o gpurun_tmp/lib20/libqttt_hip.so /tmp/r1.hip
+#                                       (with round 1's include/qttt.h: git show 637ea87:include/qttt.h)
+#   gpurun_tmp/libstamp/libqttt_hip.so  this tree with -DQTTT_DEBUG_STAMPS (per-wave timeline)
 set -u
 out=$1; mkdir -p "$out"
 b() { name=$1; shift; python3 bench.py "$@" > "$out/$name.json" 2> "$out/$name.err"; echo "$name rc=$? $(cut -c1-120 "$out/$name.json")"; }
