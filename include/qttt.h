@@ -9,7 +9,10 @@
  *     no call synchronises the device;
  *   - return value: 0 = ok, >0 = hipError_t of the launch, <0 = argument error
  *     (QTTT_ERR_NULL / QTTT_ERR_SIZE / QTTT_ERR_ACTION = a pointer not aligned as the entry needs);
- *   - the library is stateless, hence re-entrant;
+ *   - the library keeps no per-call and no per-environment state: every entry point may be called from
+ *     any number of host threads at once (on different buffers).  The one process-wide datum is the
+ *     DEFAULT launch shape (qttt_set_tuning, one relaxed atomic word); it never changes results, and a
+ *     call that carries QTTT_FLAG_SHAPE(...) in its flags does not read it;
  *   - illegal *actions* are data, not errors: they are noops exactly as env.py:36-43.
  *
  * State: an opaque device buffer of qttt_state_bytes(n) bytes for n boards (16 B/board,
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define QTTT_ABI_VERSION 2
+#define QTTT_ABI_VERSION 3
 
 #define QTTT_ERR_NULL   (-1)
 #define QTTT_ERR_SIZE   (-2)
@@ -34,6 +37,13 @@ extern "C" {
 #define QTTT_FLAG_AUTO_RESET 1u   /* a board whose previous step returned terminated is
                                      re-initialised before the action is applied (the build's
                                      throughput mode; the reference has no auto-reset) */
+
+/* Launch shape carried by the call itself (qttt_step / _observe / _random / _many, qttt_env.flags): boards
+ * per lane 1 | 2 | 4 (0 = the library's choice) and workgroup size 256 | 512 | 1024 (0 = the library's
+ * choice).  Results never depend on it.  Overrides the process-wide default of qttt_set_tuning. */
+#define QTTT_FLAG_SHAPE(boards_per_lane, workgroup_size)                                          \
+    ((((uint32_t)(boards_per_lane) & 7u) << 8) |                                                  \
+     ((workgroup_size) == 256 ? 1u << 12 : (workgroup_size) == 512 ? 2u << 12 : (workgroup_size) == 1024 ? 3u << 12 : 0u))
 
 #define QTTT_FLAG_FUSED 2u        /* qttt_step_many only: run the n_steps steps in ONE launch with the
                                      boards held in registers (same results; for replay / evaluation
@@ -70,13 +80,6 @@ int qttt_step_observe(void *state, const uint8_t *actions, const uint8_t *bits, 
                       uint8_t *terminated, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
                       uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream);
 
-/* Mapping study, not for production: the same step with ONE WAVEFRONT PER BOARD (lane 0 of each
- * wave runs the board, state staged through LDS), i.e. the floor of any wave-per-board design.
- * Same arguments and results as qttt_step (one 2^32 id range only).  DESIGN.md §2. */
-int qttt_step_wave_per_board(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
-                             uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
-                             uint8_t *terminated, int64_t n, void *stream);
-
 /* n_steps consecutive qttt_step launches enqueued back to back from C, so a replay / rollout
  * loop is not paced by the host interpreter.  Step t (0-based) reads actions + t*2n and
  * bits + t*n (when bits != NULL), uses step_idx0 + t, and writes reward + t*out_stride and
@@ -86,6 +89,17 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
                    uint32_t step_idx0, int64_t board_offset, uint32_t flags, float *reward,
                    uint8_t *terminated, int64_t out_stride, int64_t n, int32_t n_steps,
                    void *stream);
+
+/* n_steps consecutive qttt_step_random steps (policy -> collapse bit -> step, ply t keyed by the counter
+ * hash of (seed, board_offset + i, step_idx0 + t)) in ONE launch with the boards in registers: the
+ * policy -> step loop of MCTS._simulate (mcts.py:185-198) as the env's random-policy throughput mode
+ * (with QTTT_FLAG_AUTO_RESET a finished board restarts on its next ply).  Bit-identical to n_steps calls
+ * of qttt_step_random.  Step t writes actions_out + 2*t*out_stride, reward + t*out_stride and
+ * terminated + t*out_stride (out_stride in boards; 0: only the last step's outputs are written, to the
+ * first n elements).  actions_out is nullable; reward and terminated are nullable together. */
+int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
+                          uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
+                          int64_t out_stride, int64_t n, int32_t n_steps, void *stream);
 
 /* Env._observation (env.py:68-85) for n boards.
  *   classical i8[n,9]   Board.board (-1 empty else round)
@@ -103,7 +117,9 @@ int qttt_check_win(const void *state, int8_t *p1_round, int8_t *p2_round, int64_
 
 /* The Board attributes L3 callers read and assign (board.py:4-6; mcts.py:11-17,241):
  *   moves u8[n,9,2] (255 pad), n_moves u8[n], board i8[n,9], qmask u16[n,4] (qstructs in list
- *   order as 9-bit square masks, 0 pad), n_q u8[n] */
+ *   order as 9-bit square masks, 0 pad), n_q u8[n]
+ * qttt_export: every output is nullable (only what is asked for is computed and written; n_moves alone
+ * is Env.turn, env.py:65-66). */
 int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *board,
                 uint16_t *qmask, uint8_t *n_q, int64_t n, void *stream);
 int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
@@ -155,7 +171,8 @@ int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_
  *   n_children u8[n]  0 = make_move raises (children = copies of the parent), 1 = no collapse,
  *                     2 = collapse: child 0 = closing move on min(a,b) (bit 0), child 1 = on max(a,b)
  *   winner i8[n,2], terminal u8[n,2], legal u64[n,2], key i64[n,2]: as qttt_node_info, per child
- * The reference returns the two children in random order; compare as a set. */
+ * The reference returns the two children in random order; compare as a set.  winner / terminal must be
+ * 2-byte and legal / key 16-byte aligned (one vector store per pair of children; QTTT_ERR_ACTION otherwise). */
 int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *child1,
                 uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
                 int64_t *key, int64_t n, void *stream);
@@ -181,7 +198,7 @@ typedef struct qttt_env {
     int64_t  n;
     int64_t  board_offset;
     uint64_t seed;
-    uint32_t flags;                 /* QTTT_FLAG_AUTO_RESET */
+    uint32_t flags;                 /* QTTT_FLAG_AUTO_RESET | QTTT_FLAG_SHAPE(...) */
     uint32_t reserved;              /* 0 */
     float   *reward;                /* f32[n] */
     uint8_t *terminated;            /* u8[n] */
@@ -194,14 +211,17 @@ typedef struct qttt_env {
 int qttt_env_step(const qttt_env *env, uint8_t *actions, const uint8_t *bits, uint32_t step_idx,
                   int mode, void *stream);
 
-/* Launch shape of qttt_step / qttt_step_observe / qttt_step_random (results never depend on it): boards
- * per lane (1, 2 or 4) and workgroup size (256, 512 or 1024); 0 = chosen by the library from the batch
- * size (the default).  Process-wide; also settable through QTTT_STEP_BPL /
- * QTTT_STEP_BLOCK before the first call. */
+/* Process-wide DEFAULT launch shape of qttt_step / qttt_step_observe / qttt_step_random (results never
+ * depend on it): boards per lane (1, 2 or 4) and workgroup size (256, 512 or 1024); 0 = chosen by the
+ * library from the batch size.  With only boards_per_lane given the workgroup size stays
+ * the library's choice for the batch (512 for four boards per lane, the only size that exists).  Also
+ * settable through QTTT_STEP_BPL / QTTT_STEP_BLOCK before the first call.  One atomic word: safe to call
+ * while other threads launch.  Prefer QTTT_FLAG_SHAPE on the call. */
 int qttt_set_tuning(int boards_per_lane, int workgroup_size);
-/* The shape a batch of n boards is launched with under the current setting (a caller whose pointers
- * are not aligned for boards_per_lane elements gets fewer boards per lane). */
-int qttt_step_launch_shape(int64_t n, int *boards_per_lane, int *workgroup_size);
+/* The shape a batch of n boards is launched with by a call with these flags (`observe` != 0: by
+ * qttt_step_observe, whose tiles take at most two boards per lane).  A caller whose pointers are not
+ * aligned for boards_per_lane elements gets fewer boards per lane. */
+int qttt_step_launch_shape(int64_t n, uint32_t flags, int observe, int *boards_per_lane, int *workgroup_size);
 
 /* One step of every board under that policy with policy and step in ONE kernel: exactly
  * qttt_sample_actions followed by qttt_step(bits = NULL) with the same seed / step_idx /

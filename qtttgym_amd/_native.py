@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # QTTT_LIB_PATH: load another build of the same ABI (A/B diagnostics); default = the in-tree build
 LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_AUTO_RESET = 1
 FLAG_FUSED = 2
 BOARD_RECORD_BYTES = 64
@@ -34,8 +34,8 @@ SIGNATURES = {
     "qttt_step": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
     "qttt_step_observe": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i64, _vp]),
-    "qttt_step_wave_per_board": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
     "qttt_step_many": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "qttt_step_random_many": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "qttt_observe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_check_win": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_export": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -48,7 +48,7 @@ SIGNATURES = {
     "qttt_rollout": (_i32, [_vp, _u64, _u32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "qttt_encode": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_set_tuning": (_i32, [_i32, _i32]),
-    "qttt_step_launch_shape": (_i32, [_i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "qttt_step_launch_shape": (_i32, [_i64, _u32, _i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "qttt_env_step": (_i32, [ctypes.POINTER(EnvRecord), _vp, _vp, _u32, _i32, _vp]),
     "qttt_step_random": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _vp]),
     "qttt_hash": (_u64, [_u64, _u64, _u32]),
@@ -57,10 +57,18 @@ SIGNATURES = {
 _lib = None
 
 
-def step_launch_shape(n):
-    """(boards per lane, workgroup size) qttt_step uses for a batch of n boards."""
+def flag_shape(boards_per_lane=0, workgroup_size=0):
+    """include/qttt.h QTTT_FLAG_SHAPE: the launch shape carried by one call's flags (0 = the library's choice)."""
+    if boards_per_lane not in (0, 1, 2, 4) or workgroup_size not in (0, 256, 512, 1024):
+        raise ValueError("boards per lane 0|1|2|4 and workgroup size 0|256|512|1024")
+    return (boards_per_lane << 8) | ({0: 0, 256: 1, 512: 2, 1024: 3}[workgroup_size] << 12)
+
+
+def step_launch_shape(n, flags=0, observe=False):
+    """(boards per lane, workgroup size) a step call with these flags uses for a batch of n boards."""
     bpl, blk = ctypes.c_int(0), ctypes.c_int(0)
-    check(lib().qttt_step_launch_shape(int(n), ctypes.byref(bpl), ctypes.byref(blk)), "qttt_step_launch_shape")
+    check(lib().qttt_step_launch_shape(int(n), int(flags), int(bool(observe)), ctypes.byref(bpl), ctypes.byref(blk)),
+          "qttt_step_launch_shape")
     return bpl.value, blk.value
 
 

@@ -37,11 +37,15 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const u64 *pP, const u64
     __syncthreads();
     if (b0 < valid) obs_board((u32)p.v[0], (u32)(p.v[0] >> 32), (u32)q.v[0], T, b0, olut);
     if (b0 + 1u < valid) obs_board((u32)p.v[1], (u32)(p.v[1] >> 32), (u32)q.v[1], T, b0 + 1u, olut);
-    if (obs_all_phase0(obs, base)) {                      // every wave streams out the rows it wrote (see step_kernel)
+    const u32 ph = obs_all_phases(obs, base, 15u);
+    if ((ph & 3u) == 0u) {                                // every wave streams out the rows it wrote (see step_kernel)
         const u32 w0 = (threadIdx.x & ~63u) * 2u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (w0 < valid) obs_wave_copy_out<TILE_BOARDS>(otile, obs, base, w0, min(w0 + 128u, valid));
+        if (w0 < valid) {
+            if (ph == 0u) obs_wave_copy_out<TILE_BOARDS, true>(otile, obs, base, w0, min(w0 + 128u, valid));
+            else obs_wave_copy_out<TILE_BOARDS, false>(otile, obs, base, w0, min(w0 + 128u, valid));
+        }
     } else {
         __syncthreads();
         obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, base, valid);
@@ -76,45 +80,136 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void check_win_kernel(
     }
 }
 
-// Board.moves / .board / .qstructs (board.py:4-6) as arrays, straight from the packed words: the
-// move of round t is (c, c ^ x_t) for its holder c (found through the same inverse map as in
-// fast_py_hash), the board is the nibbles of the classical squares, the qstructs are the cached
-// slots.
-__global__ __launch_bounds__(QTTT_COLD_BLOCK) void export_kernel(
-    const u64 *pP, const u64 *pQ, uint8_t *moves, uint8_t *n_moves,
-    int8_t *board, uint16_t *qmask, uint8_t *n_q, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const u64 P = load_stream(&pP[i]), Q = load_stream(&pQ[i]);
-    const u32 P1 = (u32)(P >> 32), Q0 = (u32)Q;
-    const Lite s = lite_unpack(P);
-    u64 H = 0;                                                // nibble (code - 7) = holder square + 1
+// Board.moves / .board / .qstructs (board.py:4-6) as arrays, straight from the packed words, through
+// LDS tiles laid out like the outputs (as the observation): a lane builds its board's rows as packed
+// words (7 LDS stores), the wave then streams its 64 rows of every tile out with 16-byte stores.
+// Every output is nullable (VecEnv.turn() asks for n_moves alone: 8 B read, 1 B written per board).
+//   moves: the move of round t is (c, c ^ x_t) for its holder c — the one square whose nibble holds
+//     round t (child end of a live move, landing square of a collapsed one, the autofilled square for
+//     the autofill move, whose x is 0).  H inverts the holders: nibble 8 - t = holder + 1.  Rounds
+//     0..7 are then handled bytewise, four at a time (even / odd nibbles of H and of the x word), and
+//     put in round order with v_perm_b32; unused rounds read 255, 255.
+struct ExpOut {
+    uint8_t *moves;             // [n,9,2]
+    uint8_t *n_moves;           // [n]
+    int8_t *board;              // [n,9]
+    uint16_t *qmask;            // [n,4]
+    uint8_t *n_q;               // [n]
+};
+constexpr u32 exp_lds_bytes(u32 boards) {
+    return obs_tile_bytes(boards, 18) + obs_tile_bytes(boards, 9) + obs_tile_bytes(boards, 8) +
+           2u * obs_tile_bytes(boards, 1);
+}
+
+// (lo, hi) byte pairs of four rounds: h = holder + 1 per byte (0 = round not played), x = lo ^ hi per byte.
+// Returns lo bytes, hi bytes (255 where not played).
+__device__ __forceinline__ void exp_pairs(u32 h, u32 x, u32 &lo, u32 &hi) {
+    const u32 live01 = ((h + 0x0F0F0F0Fu) >> 4) & 0x01010101u;        // 1 where h != 0 (h <= 9)
+    const u32 c = h - live01;                                          // the holder square
+    const u32 o = c ^ x;                                               // the other end of its move
+    const u32 ge = (((c | 0x10101010u) - o) >> 4) & 0x01010101u;       // bytewise c >= o (both < 16)
+    const u32 gm = (ge << 8) - ge;
+    const u32 dead01 = live01 ^ 0x01010101u;
+    const u32 dead = (dead01 << 8) - dead01;                           // 0xFF where not played
+    lo = ((o & gm) | (c & ~gm)) | dead;
+    hi = ((c & gm) | (o & ~gm)) | dead;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void export_kernel(const u64 *pP, const u64 *pQ, ExpOut out, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[exp_lds_bytes(BLOCK)];
+    const int64_t base = (int64_t)blockIdx.x * BLOCK;
+    const u32 valid = (u32)min((int64_t)BLOCK, n - base);
+    const u32 b = threadIdx.x;
+    // global rows of this workgroup and the tiles that mirror them (same alignment phase, see obs_tiles)
+    uint8_t *g_mv = out.moves + base * 18, *g_bd = reinterpret_cast<uint8_t *>(out.board) + base * 9;
+    uint8_t *g_qm = reinterpret_cast<uint8_t *>(out.qmask) + base * 8, *g_nm = out.n_moves + base, *g_nq = out.n_q + base;
+    uint8_t *l_mv = tile, *l_bd = l_mv + obs_tile_bytes(BLOCK, 18), *l_qm = l_bd + obs_tile_bytes(BLOCK, 9);
+    uint8_t *l_nm = l_qm + obs_tile_bytes(BLOCK, 8), *l_nq = l_nm + obs_tile_bytes(BLOCK, 1);
+    const bool want_q = out.moves || out.qmask || out.n_q;            // plane Q: the x nibbles and the comps
+    if (b < valid) {
+        const u64 Pw = load_stream(&pP[base + b]);
+        const u64 Qw = want_q ? load_stream(&pQ[base + b]) : 0ull;
+        const u32 P1 = (u32)(Pw >> 32), Q0 = (u32)Qw;
+        const Lite s = lite_unpack(Pw);                               // the implicit autofill materialised
+        const u32 W = (u32)(s.P >> 2);                                // codes of squares 0..7
+        const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+        if (out.n_moves) (l_nm + obs_phase(g_nm))[b] = (uint8_t)s.n;
+        if (out.board) {
+            // Board.board: 15 - code where classical, -1 elsewhere (nibbles -> bytes with two v_perm)
+            const u32 ev = W & 0x0F0F0F0Fu, od = (W >> 4) & 0x0F0F0F0Fu;
+            const u32 c03 = __builtin_amdgcn_perm(od, ev, 0x05010400u), c47 = __builtin_amdgcn_perm(od, ev, 0x07030602u);
+            const u32 t03 = __umul24(s.cl & 0xFu, 0x204081u) & 0x01010101u;
+            const u32 t47 = __umul24((s.cl >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+            const u32 m03 = (t03 << 8) - t03, m47 = (t47 << 8) - t47;
+            const u64 o07 = (u64)((c03 ^ 0x0F0F0F0Fu) | ~m03) | ((u64)((c47 ^ 0x0F0F0F0Fu) | ~m47) << 32);
+            uint8_t *r = l_bd + obs_phase(g_bd) + b * 9u;
+            __builtin_memcpy(r, &o07, 8);
+            r[8] = (uint8_t)((s.cl & 0x100u) ? (c8 ^ 0xFu) : 0xFFu);
+        }
+        if (out.moves) {
+            u64 H = 0;                                                // nibble (code - 7) = holder square + 1
 #pragma unroll
-    for (u32 v = 0; v < 9; ++v) {
-        const u32 c = (u32)(s.P >> (4u * v + 2u)) & 0xFu;
-        H |= (u64)(v + 1u) << ((4u * c + 36u) & 63u);
-        board[i * 9 + v] = (s.cl >> v & 1u) ? (int8_t)(15u - c) : (int8_t)-1;
+            for (u32 v = 0; v < 8; ++v) H |= (u64)(v + 1u) << ((((W >> (4u * v)) & 0xFu) * 4u + 36u) & 63u);
+            H |= 9ull << ((c8 * 4u + 36u) & 63u);
+            const u32 last_x = (P1 >> P1_LX_SHIFT) & 0xFu;
+            const bool nine = s.n_real == 9u;
+            const u32 Hs = (u32)(H >> 4);                             // nibble 7 - t = holder + 1 of round t <= 7
+            const u32 X = rotr32(Q0, 2u) ^ (nine ? last_x << 28 : 0u); // nibble 7 - t = x of round t (round 8's x undone)
+            u32 lo_e, hi_e, lo_o, hi_o;                               // bytes 0..3 = rounds 7,5,3,1 / 6,4,2,0
+            exp_pairs(Hs & 0x0F0F0F0Fu, X & 0x0F0F0F0Fu, lo_e, hi_e);
+            exp_pairs((Hs >> 4) & 0x0F0F0F0Fu, (X >> 4) & 0x0F0F0F0Fu, lo_o, hi_o);
+            const u32 A = __builtin_amdgcn_perm(hi_o, lo_o, 0x06020703u);   // rounds 0, 2 as (lo, hi) pairs
+            const u32 B = __builtin_amdgcn_perm(hi_e, lo_e, 0x06020703u);   // rounds 1, 3
+            const u32 C = __builtin_amdgcn_perm(hi_o, lo_o, 0x04000501u);   // rounds 4, 6
+            const u32 D = __builtin_amdgcn_perm(hi_e, lo_e, 0x04000501u);   // rounds 5, 7
+            const u64 m03 = (u64)__builtin_amdgcn_perm(B, A, 0x05040100u) | ((u64)__builtin_amdgcn_perm(B, A, 0x07060302u) << 32);
+            const u64 m47 = (u64)__builtin_amdgcn_perm(D, C, 0x05040100u) | ((u64)__builtin_amdgcn_perm(D, C, 0x07060302u) << 32);
+            const u32 h8 = (u32)H & 0xFu;                             // round 8: the last real move or the autofill (x = 0)
+            const u32 c = h8 - 1u, o = c ^ (nine ? last_x : 0u);
+            const uint16_t m8 = h8 ? (uint16_t)(min(c, o) | (max(c, o) << 8)) : (uint16_t)0xFFFFu;
+            uint8_t *r = l_mv + obs_phase(g_mv) + b * 18u;
+            __builtin_memcpy(r, &m03, 8);
+            __builtin_memcpy(r + 8, &m47, 8);
+            __builtin_memcpy(r + 16, &m8, 2);
+        }
+        if (out.qmask || out.n_q) {
+            const u64 comps = (Qw >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
+            const u32 c32 = (u32)comps;
+            if (out.qmask) {
+                const u64 q = (u64)((c32 & 0x1FFu) | ((c32 << 7) & 0x01FF0000u)) |
+                              ((u64)(((c32 >> 18) & 0x1FFu) | ((u32)(comps >> 11) & 0x01FF0000u)) << 32);
+                __builtin_memcpy(l_qm + obs_phase(g_qm) + b * 8u, &q, 8);
+            }
+            if (out.n_q) {                                            // slots are compact: count the non-empty ones
+                const u32 nz = ((((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u) | ((comps >> 27) ? 1u : 0u);
+                (l_nq + obs_phase(g_nq))[b] = (uint8_t)__builtin_popcount(nz);
+            }
+        }
     }
-#pragma unroll
-    for (u32 t = 0; t < 9; ++t) {
-        const u32 h = (u32)(H >> (4u * (8u - t))) & 0xFu;
-        const u32 c = h ? h - 1u : 0u;
-        const u32 x = (t >= s.n_real) ? 0u : cold_move_x(Q0, P1, s.n_real, t);     // autofill = (idx, idx)
-        const u32 o = c ^ x;
-        const bool used = t < s.n;
-        moves[i * 18 + t * 2] = used ? (uint8_t)min(c, o) : (uint8_t)255;
-        moves[i * 18 + t * 2 + 1] = used ? (uint8_t)max(c, o) : (uint8_t)255;
+    const uintptr_t all = (out.moves ? (uintptr_t)g_mv : 0) | (out.board ? (uintptr_t)g_bd : 0) |
+                          (out.qmask ? (uintptr_t)g_qm : 0) | (out.n_moves ? (uintptr_t)g_nm : 0) | (out.n_q ? (uintptr_t)g_nq : 0);
+    if ((all & 3u) == 0u) {                                           // every wave streams out the rows it wrote
+        const u32 w0 = threadIdx.x & ~63u, w1 = min(w0 + 64u, valid);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (w0 < valid) {
+#define QTTT_XCO(PTR, G, L, ROW) do { if (PTR) { if ((all & 15u) == 0u) wave_copy_out16(G, L, w0 * (ROW), w1 * (ROW)); else wave_copy_out(G, L, w0 * (ROW), w1 * (ROW)); } } while (0)
+            QTTT_XCO(out.moves, g_mv, l_mv, 18u);
+            QTTT_XCO(out.board, g_bd, l_bd, 9u);
+            QTTT_XCO(out.qmask, g_qm, l_qm, 8u);
+            QTTT_XCO(out.n_moves, g_nm, l_nm, 1u);
+            QTTT_XCO(out.n_q, g_nq, l_nq, 1u);
+#undef QTTT_XCO
+        }
+    } else {
+        __syncthreads();
+        if (out.moves) tile_copy_out<BLOCK>(g_mv, l_mv, valid * 18u);
+        if (out.board) tile_copy_out<BLOCK>(g_bd, l_bd, valid * 9u);
+        if (out.qmask) tile_copy_out<BLOCK>(g_qm, l_qm, valid * 8u);
+        if (out.n_moves) tile_copy_out<BLOCK>(g_nm, l_nm, valid);
+        if (out.n_q) tile_copy_out<BLOCK>(g_nq, l_nq, valid);
     }
-    n_moves[i] = (uint8_t)s.n;
-    const u64 comps = (Q >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
-    u32 nq = 0;
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k) {
-        const u32 m = (u32)(comps >> (9u * k)) & 0x1FFu;
-        qmask[i * 4 + k] = (uint16_t)m;
-        nq += m != 0u;
-    }
-    n_q[i] = (uint8_t)nq;
 }
 
 // Builds the unpacked board (incl. the rooted forest) from Board attributes assigned by a caller

@@ -283,23 +283,31 @@ __device__ inline void fill_pyhash_lut(u64 *dst) {
     for (u32 w = threadIdx.x; w < PYHASH_LUT_WORDS; w += BLOCK) dst[w] = src[w];
 }
 
-__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0, const u64 *tbl) {
-    u64 acc = PYH_P5;
-    const u32 W = (u32)(s.P >> 2);                                  // codes of squares 0..7
-    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
-#pragma unroll
-    for (u32 v = 0; v < 9; ++v) {
-        const u32 c = v < 8u ? (W >> (4u * v)) & 0xFu : c8;
-        acc = pyh_step(acc, tbl[(s.cl >> v & 1u) ? 16u - c : 0u]);  // board[value + 1], value = 15 - c
+// One board's walk over its moves in round order: round t is held by the one square whose code is
+// 15 - t (zero nibble of W ^ 0x1111_1111 * code; the lowest flag of the borrow trick is always a true
+// zero; no flag = square 8), and is (c, c ^ x_t).  x nibbles: round 0 in bits 0..3 of Qr, round t >= 1 at
+// 32 - 4t.
+struct PyHashWalk {
+    u64 acc;
+    u32 W, c8, Qr, kk, sh, n8, last_x;
+    bool nine_real, nine;
+    __device__ __forceinline__ void init(const Lite &s, u32 P1_stored, u32 Q0) {
+        acc = PYH_P5;
+        W = (u32)(s.P >> 2);                                        // codes of squares 0..7
+        c8 = (u32)(s.P >> 34) & 0xFu;
+        last_x = (P1_stored >> P1_LX_SHIFT) & 0xFu;
+        nine_real = s.n_real == 9u;
+        nine = s.n == 9u;
+        Qr = rotr32(Q0, 30u) ^ (nine_real ? last_x : 0u);           // round 8's x was XORed onto round 0's
+        n8 = min(s.n, 8u);
+        kk = 0xFFFFFFFFu;
+        sh = 0u;
     }
-    // moves in round order: round t is held by the one square whose code is 15 - t (zero nibble of
-    // W ^ 0x1111_1111 * code; the lowest flag of the borrow trick is always a true zero; no flag =
-    // square 8), and is (c, c ^ x_t).  x nibbles: round 0 in bits 0..3 of Qr, round t >= 1 at 32 - 4t.
-    const u32 last_x = (P1_stored >> P1_LX_SHIFT) & 0xFu;
-    const u32 Qr = rotr32(Q0, 30u) ^ (s.n_real == 9u ? last_x : 0u);  // round 8's x was XORed onto round 0's
-    const u32 n8 = min(s.n, 8u);
-    u32 kk = 0xFFFFFFFFu, sh = 0u;
-    for (u32 t = 0; t < n8; ++t) {                                  // (an autofill move is always round 8)
+    __device__ __forceinline__ void board_elem(u32 v, u32 cl, const u64 *tbl) {
+        const u32 c = v < 8u ? (W >> (4u * v)) & 0xFu : c8;
+        acc = pyh_step(acc, tbl[(cl >> v & 1u) ? 16u - c : 0u]);    // board[value + 1], value = 15 - c
+    }
+    __device__ __forceinline__ void move_elem(u32 t, const u64 *tbl) {   // t < n8 (an autofill move is always round 8)
         const u32 z = W ^ kk;
         const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
         const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
@@ -308,14 +316,46 @@ __device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u3
         kk -= 0x11111111u;
         sh = (sh - 4u) & 31u;
     }
-    if (s.n == 9u) {
-        const u32 z = W ^ 0x77777777u;
-        const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
-        const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
-        const u32 o = min(c ^ (s.n_real == 9u ? last_x : 0u), 8u);  // autofill = (idx, idx)
-        acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + 8u]);
+    __device__ __forceinline__ int64_t finish(u32 n, const u64 *tbl) {
+        if (nine) {
+            const u32 z = W ^ 0x77777777u;
+            const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
+            const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
+            const u32 o = min(c ^ (nine_real ? last_x : 0u), 8u);   // autofill = (idx, idx)
+            acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + 8u]);
+        }
+        return (int64_t)pyh_fin(acc, 9u + n);
     }
-    return (int64_t)pyh_fin(acc, 9u + s.n);
+};
+
+__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0, const u64 *tbl) {
+    PyHashWalk w;
+    w.init(s, P1_stored, Q0);
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) w.board_elem(v, s.cl, tbl);
+    for (u32 t = 0; t < w.n8; ++t) w.move_elem(t, tbl);
+    return w.finish(s.n, tbl);
+}
+
+// Two boards at once: the hash is a chain of dependent steps (add, rotate, 64-bit multiply, next table
+// address) and every step waits on a 64-bit LDS gather, so one chain per lane leaves the SIMD waiting
+// (~6.6 cycles per instruction at 8 waves per SIMD); two independent chains in one
+// instruction stream fill those slots.  The rounds both boards have are walked together, the rest of
+// the longer game on its own (boards of one batch are usually at similar depths).
+__device__ __forceinline__ void fast_py_hash_pair(const Lite &sa, u32 P1a, u32 Q0a, const Lite &sb, u32 P1b, u32 Q0b,
+                                                  const u64 *tbl, int64_t &ka, int64_t &kb) {
+    PyHashWalk a, b;
+    a.init(sa, P1a, Q0a);
+    b.init(sb, P1b, Q0b);
+#pragma unroll
+    for (u32 v = 0; v < 9; ++v) { a.board_elem(v, sa.cl, tbl); b.board_elem(v, sb.cl, tbl); }
+    const u32 both = min(a.n8, b.n8);
+    u32 t = 0;
+    for (; t < both; ++t) { a.move_elem(t, tbl); b.move_elem(t, tbl); }
+    for (u32 u = t; u < a.n8; ++u) a.move_elem(u, tbl);
+    for (u32 u = t; u < b.n8; ++u) b.move_elem(u, tbl);
+    ka = a.finish(sa.n, tbl);
+    kb = b.finish(sb.n, tbl);
 }
 
 }  // namespace

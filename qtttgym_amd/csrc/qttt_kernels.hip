@@ -47,6 +47,7 @@
 // Files: qttt_state.h (layout, loads/stores, shared tables) -> qttt_step_core.h (the step) ->
 // qttt_observation.h -> qttt_step_kernels.h; qttt_board_forms.h (unpacked views, winner, legal mask,
 // tuple hash) -> qttt_aux_kernels.h, qttt_mcts_kernels.h; this file: launch logic + the C ABI.
+#include <atomic>
 #include "qttt_step_kernels.h"
 #include "qttt_aux_kernels.h"
 #include "qttt_mcts_kernels.h"
@@ -76,23 +77,35 @@ inline void auto_tuning(int64_t n, int &bpl, int &blk) {
     else if (n <= 1536 * 1024) { bpl = 2; blk = 1024; }
     else { bpl = 2; blk = 256; }
 }
-// overrides (bench / profiling / tests): boards per lane 1|2|4 and workgroup size 256|512|1024, 0 = by
-// batch size.  Initialised from QTTT_STEP_BPL / QTTT_STEP_BLOCK, changeable through qttt_set_tuning().
-inline int &tuning_bpl() {
-    static int v = [] {
-        int k = 0;
-        if (const char *e = getenv("QTTT_STEP_BPL")) { int q = atoi(e); if (q == 1 || q == 2 || q == 4) k = q; }
-        return k;
-    }();
+// Process-wide DEFAULT launch shape (bench / profiling): boards per lane 1|2|4 and workgroup size
+// 256|512|1024, 0 = by batch size.  Initialised from QTTT_STEP_BPL / QTTT_STEP_BLOCK, changeable through
+// qttt_set_tuning(); one relaxed atomic word (bpl | block << 8), so concurrent callers never race on it.
+// A call that carries QTTT_FLAG_SHAPE(...) in its flags does not look at it at all.
+inline std::atomic<int> &tuning_word() {
+    static std::atomic<int> v([] {
+        int bpl = 0, blk = 0;
+        if (const char *e = getenv("QTTT_STEP_BPL")) { int q = atoi(e); if (q == 1 || q == 2 || q == 4) bpl = q; }
+        if (const char *e = getenv("QTTT_STEP_BLOCK")) { int q = atoi(e); if (q == 256 || q == 512 || q == 1024) blk = q; }
+        return bpl | (blk << 8);
+    }());
     return v;
 }
-inline int &tuning_block() {
-    static int v = [] {
-        int k = 0;
-        if (const char *e = getenv("QTTT_STEP_BLOCK")) { int q = atoi(e); if (q == 256 || q == 512 || q == 1024) k = q; }
-        return k;
-    }();
-    return v;
+// the shape one call is launched with: the call's own QTTT_FLAG_SHAPE bits, else the process default,
+// else the table; `observe`: the observation tiles are sized for <= 2 boards per lane
+inline void resolve_shape(int64_t n, uint32_t flags, bool observe, int &bpl, int &blk) {
+    int f_bpl = (int)((flags >> 8) & 7u), f_blk = 0;
+    switch ((flags >> 12) & 3u) { case 1: f_blk = 256; break; case 2: f_blk = 512; break; case 3: f_blk = 1024; break; default: break; }
+    if (f_bpl != 1 && f_bpl != 2 && f_bpl != 4) f_bpl = 0;
+    if (!f_bpl && !f_blk) {
+        const int w = tuning_word().load(std::memory_order_relaxed);
+        f_bpl = w & 0xFF;
+        f_blk = w >> 8;
+    }
+    auto_tuning(n, bpl, blk);
+    if (f_bpl) bpl = f_bpl;
+    if (f_blk) blk = f_blk;
+    if (observe && bpl > 2) bpl = 2;
+    if (bpl == 4) blk = QTTT_BLOCK;                      // four boards per lane exist with 512 threads only
 }
 
 inline int grid_for(int64_t n) { return (int)((n + QTTT_BLOCK - 1) / QTTT_BLOCK); }
@@ -121,21 +134,14 @@ int qttt_debug_set_stamps(void *buf) {
 int qttt_set_tuning(int boards_per_lane, int workgroup_size) {
     if (!(boards_per_lane == 0 || boards_per_lane == 1 || boards_per_lane == 2 || boards_per_lane == 4)) return QTTT_ERR_SIZE;
     if (!(workgroup_size == 0 || workgroup_size == 256 || workgroup_size == 512 || workgroup_size == 1024)) return QTTT_ERR_SIZE;
-    tuning_bpl() = boards_per_lane;
-    tuning_block() = workgroup_size;
+    tuning_word().store(boards_per_lane | (workgroup_size << 8), std::memory_order_relaxed);
     return 0;
 }
 
-int qttt_step_launch_shape(int64_t n, int *boards_per_lane, int *workgroup_size) {
+int qttt_step_launch_shape(int64_t n, uint32_t flags, int observe, int *boards_per_lane, int *workgroup_size) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (!boards_per_lane || !workgroup_size) return QTTT_ERR_NULL;
-    int bpl, blk;
-    auto_tuning(n, bpl, blk);
-    if (tuning_bpl()) { bpl = tuning_bpl(); blk = QTTT_BLOCK; }
-    if (tuning_block()) blk = tuning_block();
-    if (bpl == 4) blk = QTTT_BLOCK;
-    *boards_per_lane = bpl;
-    *workgroup_size = blk;
+    resolve_shape(n, flags, observe != 0, *boards_per_lane, *workgroup_size);
     return 0;
 }
 
@@ -171,10 +177,9 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     uint16_t *a16 = reinterpret_cast<uint16_t *>(actions);
     u32 *rb = reinterpret_cast<u32 *>(reward);
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
-    int bpl_pref, blk_sel;
-    qttt_step_launch_shape(n, &bpl_pref, &blk_sel);
+    int bpl_max, blk_sel;
+    resolve_shape(n, flags, obs != nullptr, bpl_max, blk_sel);
     // widest boards-per-lane the caller's pointers are aligned for (the planes always are)
-    int bpl_max = obs ? (bpl_pref > 2 ? 2 : bpl_pref) : bpl_pref;              // the tiles are sized for <= 2
     auto aligned = [&](int k) {
         return ((uintptr_t)actions % (2u * k)) == 0 && ((uintptr_t)reward % (4u * k)) == 0 &&
                ((uintptr_t)terminated % (unsigned)k) == 0 && (!bits || ((uintptr_t)bits % (unsigned)k) == 0);
@@ -248,30 +253,6 @@ int qttt_step_observe(void *state, const uint8_t *actions, const uint8_t *bits, 
                        reward, terminated, n, stream, false, &o);
 }
 
-int qttt_step_wave_per_board(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,
-                             uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
-                             uint8_t *terminated, int64_t n, void *stream) {
-    if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
-    if (n == 0) return 0;
-    if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
-    if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;
-    const u64 first = (u64)board_offset;
-    if ((first >> 32) != ((first + (u64)n - 1u) >> 32)) return QTTT_ERR_SIZE;   // study kernel: one id range
-    Planes p = planes(state, n);
-    const u32 key_fold = (u32)launch_key(seed, step_idx) ^ ((u32)(first >> 32) * 0x9E3779B9u);
-    const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
-    dim3 g((unsigned)((n + 3) / 4)), b(256);
-    hipStream_t s = (hipStream_t)stream;
-    const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
-    u32 *rb = reinterpret_cast<u32 *>(reward);
-#define QTTT_WPB(HB, AR) hipLaunchKernelGGL((step_wave_per_board_kernel<HB, AR>), g, b, 0, s, p.P, p.Q, \
-                                            a16, bits, key_fold, (u32)first, rb, terminated, n)
-    if (bits) { if (ar) QTTT_WPB(true, true); else QTTT_WPB(true, false); }
-    else      { if (ar) QTTT_WPB(false, true); else QTTT_WPB(false, false); }
-#undef QTTT_WPB
-    return launch_status();
-}
-
 int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
                      uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
                      int64_t n, void *stream) {
@@ -334,6 +315,28 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
     return 0;
 }
 
+int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset, uint32_t flags,
+                          uint8_t *actions_out, float *reward, uint8_t *terminated, int64_t out_stride,
+                          int64_t n, int32_t n_steps, void *stream) {
+    if (n < 0 || board_offset < 0 || n_steps < 0 || out_stride < 0) return QTTT_ERR_SIZE;
+    if (n == 0 || n_steps == 0) return 0;
+    if (!state || (reward == nullptr) != (terminated == nullptr)) return QTTT_ERR_NULL;
+    if (((uintptr_t)actions_out & 1u) || ((uintptr_t)reward & 3u)) return QTTT_ERR_ACTION;
+    Planes p = planes(state, n);
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t *a16 = reinterpret_cast<uint16_t *>(actions_out);
+    u32 *rb = reinterpret_cast<u32 *>(reward);
+    const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
+    // 256-thread workgroups: the finest spread of a small batch over the 256 CUs (4 096 boards = 16 CUs
+    // with 512 threads, 16 with 256 — but 262 144 boards = 1 024 workgroups, four per CU, instead of two)
+#define QTTT_RF(AR) hipLaunchKernelGGL((step_random_fused_kernel<256, AR>), dim3(blocks_for(n, 256)), dim3(256), 0, s, \
+                                       p.P, p.Q, (u64)seed, step_idx0, (u64)board_offset, a16, rb, terminated,        \
+                                       out_stride, n, n_steps)
+    if (ar) QTTT_RF(true); else QTTT_RF(false);
+#undef QTTT_RF
+    return launch_status();
+}
+
 int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,
                  uint8_t *q_p2, uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
@@ -345,7 +348,8 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     // 256-thread workgroups: best or tied at every batch size for this write-heavy kernel (us per launch,
     // 256 / 512 / 1024 threads: 65 536 boards 3.9 / 4.3 / 5.6, 262 144: 4.9 / 4.8 / 6.2, 1 M: 9.0 / 9.3 / 9.6,
     // 4 M: 33.6 / 34.8 / 38.6)
-    const int blk = tuning_block() ? tuning_block() : 256;
+    const int blk_default = tuning_word().load(std::memory_order_relaxed) >> 8;
+    const int blk = blk_default ? blk_default : 256;
 #define QTTT_OBSERVE(BLK) hipLaunchKernelGGL((observe_kernel<BLK>), dim3((unsigned)((n + 2 * (BLK) - 1) / (2 * (BLK)))), \
                                              dim3(BLK), 0, (hipStream_t)stream, p.P, p.Q, o, n)
     if (blk == 1024) QTTT_OBSERVE(1024);
@@ -369,10 +373,13 @@ int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *boa
                 uint16_t *qmask, uint8_t *n_q, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
-    if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
+    if (!state) return QTTT_ERR_NULL;
+    if (!moves && !n_moves && !board && !qmask && !n_q) return 0;            // nothing asked for
+    if ((uintptr_t)qmask & 1u) return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(export_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.P, p.Q, moves, n_moves, board, qmask, n_q, n);
+    const ExpOut o = {moves, n_moves, board, qmask, n_q};
+    hipLaunchKernelGGL((export_kernel<QTTT_COLD_BLOCK>), dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0,
+                       (hipStream_t)stream, p.P, p.Q, o, n);
     return launch_status();
 }
 
@@ -423,7 +430,7 @@ int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_
     if (n == 0) return 0;
     if (!state || !winner || !terminal || !legal || !key) return QTTT_ERR_NULL;
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(node_info_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(node_info_kernel, dim3(grid_for((n + 1) / 2)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
                        p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
     return launch_status();
 }
@@ -435,6 +442,9 @@ int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *
     if (n == 0) return 0;
     if (!state || !action36 || !child0 || !child1 || !n_children || !winner || !terminal || !legal || !key)
         return QTTT_ERR_NULL;
+    // the per-child rows [n,2] are written as one vector per pair
+    if (((uintptr_t)winner & 1u) || ((uintptr_t)terminal & 1u) || ((uintptr_t)legal & 15u) || ((uintptr_t)key & 15u))
+        return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
     hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
                        p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner,

@@ -19,44 +19,83 @@ struct PairLut {
 };
 __constant__ PairLut g_pair_lut = PairLut();
 
+// Two boards per lane (one 16-byte load per plane, 16-byte stores of the two legal masks and the two
+// keys): the CPython tuple hash is a dependent chain per board, two chains in one lane interleave
+// (fast_py_hash_pair).  The last board of an odd batch is handled alone.
 __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
     __shared__ u64 ltbl[512];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
-    const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;   // before the table fill
+    const int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;   // boards 2j, 2j + 1
+    const int64_t i0 = 2 * j;
+    typedef Vec<u64, 2> V64;
+    V64 p, q;
+    p.v[0] = p.v[1] = q.v[0] = q.v[1] = 0ull;
+    if (i0 + 1 < n) {                                                   // requested before the table fills
+        p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]);
+        q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);
+    } else if (i0 < n) {
+        p.v[0] = pP[i0];
+        q.v[0] = pQ[i0];
+    }
     fill_pyhash_lut<QTTT_BLOCK>(htbl);
     fill_legal_lut<QTTT_BLOCK>(ltbl);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
-    if (i >= n) return;
-    const Lite s = lite_unpack(P);
-    int w, t;
-    lite_update_winner(s, lut, w, t);
-    winner[i] = (int8_t)w;
-    terminal[i] = (uint8_t)t;
-    legal[i] = ltbl[s.cl];
-    key[i] = fast_py_hash(s, (u32)(P >> 32), (u32)Q, htbl);
+    if (i0 >= n) return;
+    const Lite sa = lite_unpack(p.v[0]), sb = lite_unpack(p.v[1]);
+    int wa, ta, wb, tb;
+    lite_update_winner(sa, lut, wa, ta);
+    lite_update_winner(sb, lut, wb, tb);
+    int64_t ka, kb;
+    fast_py_hash_pair(sa, (u32)(p.v[0] >> 32), (u32)q.v[0], sb, (u32)(p.v[1] >> 32), (u32)q.v[1], htbl, ka, kb);
+    const u64 la = ltbl[sa.cl], lb = ltbl[sb.cl];
+    const bool two = i0 + 1 < n;
+    if (two && ((reinterpret_cast<uintptr_t>(winner) | reinterpret_cast<uintptr_t>(terminal)) & 1u) == 0u) {
+        reinterpret_cast<uint16_t *>(winner)[j] = (uint16_t)((u32)(wa & 0xFF) | ((u32)(wb & 0xFF) << 8));
+        reinterpret_cast<uint16_t *>(terminal)[j] = (uint16_t)((u32)ta | ((u32)tb << 8));
+    } else {
+        winner[i0] = (int8_t)wa;
+        terminal[i0] = (uint8_t)ta;
+        if (two) { winner[i0 + 1] = (int8_t)wb; terminal[i0 + 1] = (uint8_t)tb; }
+    }
+    if (two && ((reinterpret_cast<uintptr_t>(legal) | reinterpret_cast<uintptr_t>(key)) & 15u) == 0u) {
+        V64 l2, k2;
+        l2.v[0] = la; l2.v[1] = lb;
+        k2.v[0] = (u64)ka; k2.v[1] = (u64)kb;
+        store_stream(&reinterpret_cast<V64 *>(legal)[j], l2);
+        store_stream(&reinterpret_cast<V64 *>(key)[j], k2);
+    } else {
+        legal[i0] = la;
+        key[i0] = ka;
+        if (two) { legal[i0 + 1] = lb; key[i0 + 1] = kb; }
+    }
 }
 
 // MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
-// re-sampling make_move until the other branch appears.
+// re-sampling make_move until the other branch appears.  The two children's bookkeeping (winner, legal
+// mask, key) is computed as a pair — two independent hash chains in one lane, as in node_info — and
+// masked by n_children afterwards (child 1 is a valid state even when there is no collapse: it equals
+// child 0).
 __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
     const u64 *pP, const u64 *pQ, const uint8_t *action36,
     u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, uint8_t *n_children,
     int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    __shared__ u64 ltbl[512];
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
-    const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
+    const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;  // requested before the table fills
     const u32 a = i < n ? (u32)action36[i] : 0u;
     fill_pyhash_lut<QTTT_BLOCK>(htbl);
+    fill_legal_lut<QTTT_BLOCK>(ltbl);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
     const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
     u64 kidP[2], kidQ[2];
+#pragma unroll
     for (u32 bit = 0; bit < 2; ++bit) {
         u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
         step_core<false>(P0, P1, Q0, Q1, act, bit, lut);
@@ -69,23 +108,25 @@ __global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
     const u32 cl_after = ((u32)(kidP[0] >> 32) >> P1_CL_SHIFT) & 0x1FFu;
     const u32 kids = n_after == n_before ? 0u : (cl_after != cl_before ? 2u : 1u);   // mcts.py:245
     n_children[i] = (uint8_t)kids;
-    c0P[i] = kidP[0]; c0Q[i] = kidQ[0];
-    c1P[i] = kidP[1]; c1Q[i] = kidQ[1];
-    for (u32 c = 0; c < 2; ++c) {
-        int w = -1, t = 0;
-        u64 lm = 0;
-        int64_t k = 0;
-        if (c < kids) {
-            const Lite s = lite_unpack(kidP[c]);
-            lite_update_winner(s, lut, w, t);
-            lm = fast_legal_mask(s.cl);
-            k = fast_py_hash(s, (u32)(kidP[c] >> 32), (u32)kidQ[c], htbl);
-        }
-        winner[i * 2 + c] = (int8_t)w;
-        terminal[i * 2 + c] = (uint8_t)t;
-        legal[i * 2 + c] = lm;
-        key[i * 2 + c] = k;
-    }
+    store_stream(&c0P[i], kidP[0]); store_stream(&c0Q[i], kidQ[0]);
+    store_stream(&c1P[i], kidP[1]); store_stream(&c1Q[i], kidQ[1]);
+    const Lite s0 = lite_unpack(kidP[0]), s1 = lite_unpack(kidP[1]);
+    int w0, t0, w1, t1;
+    lite_update_winner(s0, lut, w0, t0);
+    lite_update_winner(s1, lut, w1, t1);
+    int64_t k0, k1;
+    fast_py_hash_pair(s0, (u32)(kidP[0] >> 32), (u32)kidQ[0], s1, (u32)(kidP[1] >> 32), (u32)kidQ[1], htbl, k0, k1);
+    const bool h0 = kids >= 1u, h1 = kids >= 2u;
+    const u32 wv = (u32)((h0 ? w0 : -1) & 0xFF) | ((u32)((h1 ? w1 : -1) & 0xFF) << 8);
+    const u32 tv = (h0 ? (u32)t0 : 0u) | ((h1 ? (u32)t1 : 0u) << 8);
+    reinterpret_cast<uint16_t *>(winner)[i] = (uint16_t)wv;            // [n,2] rows: 2-byte / 16-byte aligned by the host check
+    reinterpret_cast<uint16_t *>(terminal)[i] = (uint16_t)tv;
+    typedef Vec<u64, 2> V64;
+    V64 l2, k2;
+    l2.v[0] = h0 ? ltbl[s0.cl] : 0ull; l2.v[1] = h1 ? ltbl[s1.cl] : 0ull;
+    k2.v[0] = h0 ? (u64)k0 : 0ull;     k2.v[1] = h1 ? (u64)k1 : 0ull;
+    store_stream(&reinterpret_cast<V64 *>(legal)[i], l2);
+    store_stream(&reinterpret_cast<V64 *>(key)[i], k2);
 }
 
 // MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
@@ -96,21 +137,11 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     int8_t *result, uint8_t *plies, u64 *fP, u64 *fQ, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    // nth9[m * 9 + r] = the r-th empty square of the 9-bit mask m: nine plies of policy per board make a
-    // full table (4.5 KB, computed here: thread m writes row m) cheaper than the two-level lookup of
-    // policy_nth()
     __shared__ uint8_t nth9[512 * 9];
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
     fill_policy_lut<QTTT_BLOCK>(plut);
-    for (u32 m = threadIdx.x; m < 512u; m += QTTT_BLOCK) {
-        u32 r = 0;
-#pragma unroll
-        for (u32 v = 0; v < 9; ++v) {
-            nth9[m * 9u + r] = (uint8_t)v;                 // kept only if bit v is set (r advances), else overwritten
-            r += m >> v & 1u;                              // r <= v inside the loop: the store stays in row m
-        }
-    }
+    fill_nth9<QTTT_BLOCK>(nth9);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
@@ -122,10 +153,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
         const u64 key = launch_key(seed, step_idx0 + p);
         const u32 h1 = lowbias32(id ^ (u32)key);
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
-        // policy_action() with the full table: the k-th legal pair (i < j) -> squares (a < b)
-        const u32 e = (u32)__builtin_popcount(empty);
-        const u32 ij = plut[e * 36u + __umulhi(h2, (e * (e - 1u)) >> 1)];
-        const u32 act = (u32)nth9[empty * 9u + (ij & 0xFu)] | ((u32)nth9[empty * 9u + (ij >> 4)] << 8);
+        const u32 act = policy_action_nth9(plut, nth9, empty, h2);   // the k-th legal pair, squares a < b
         step_core<false, true>(P0, P1, Q0, Q1, act, h1 >> 31, lut);   // legal and sorted
         played += 1u;
     }

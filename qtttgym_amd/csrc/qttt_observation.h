@@ -60,26 +60,45 @@ __device__ inline void wave_copy_out(uint8_t *gdst, const uint8_t *tile16, u32 b
     if (k < end) gdst[k] = tile16[k];
 }
 
-// true iff every tile of this workgroup starts on a dword in global memory (block-uniform)
-__device__ __forceinline__ bool obs_all_phase0(const ObsOut &o, int64_t first) {
-    return ((obs_phase(reinterpret_cast<const uint8_t *>(o.classical) + first * 9) | obs_phase(o.q_p1 + first * 10) |
-             obs_phase(o.q_p2 + first * 8) | obs_phase(o.q_p1_len + first) | obs_phase(o.q_p2_len + first) |
-             obs_phase(o.turn + first)) == 0u);
+// The same with 16-byte pieces (one global_store_dwordx4 per lane = 1 KB per wave instruction) when the
+// wave's span starts on a 16-byte boundary on both sides; the tail (< 16 bytes x 64) goes as dwords + bytes.
+__device__ inline void wave_copy_out16(uint8_t *gdst, const uint8_t *tile16, u32 begin, u32 end) {
+    const u32 lane = threadIdx.x & 63u;
+    u32x4 *gq = reinterpret_cast<u32x4 *>(gdst);
+    const u32x4 *sq = reinterpret_cast<const u32x4 *>(tile16);
+    const u32 q0 = begin >> 4, q1 = end >> 4;                       // begin is a multiple of 16
+    for (u32 k = q0 + lane; k < q1; k += 64u) __builtin_nontemporal_store(sq[k], &gq[k]);
+    const u32 t0 = q1 << 4;                                          // < 16 bytes left: at most 3 dwords + 3 bytes
+    const u32 kd = (t0 >> 2) + lane;
+    if (kd < (end >> 2)) reinterpret_cast<u32 *>(gdst)[kd] = reinterpret_cast<const u32 *>(tile16)[kd];
+    const u32 kb = (end & ~3u) + lane;
+    if (kb < end) gdst[kb] = tile16[kb];
 }
 
-template <u32 BOARDS>
+// true iff every tile of this workgroup starts on a dword in global memory (block-uniform)
+__device__ __forceinline__ u32 obs_all_phases(const ObsOut &o, int64_t first, u32 mask) {
+    return (u32)((uintptr_t)(reinterpret_cast<const uint8_t *>(o.classical) + first * 9) | (uintptr_t)(o.q_p1 + first * 10) |
+                 (uintptr_t)(o.q_p2 + first * 8) | (uintptr_t)(o.q_p1_len + first) | (uintptr_t)(o.q_p2_len + first) |
+                 (uintptr_t)(o.turn + first)) & mask;
+}
+__device__ __forceinline__ bool obs_all_phase0(const ObsOut &o, int64_t first) { return obs_all_phases(o, first, 3u) == 0u; }
+
+// VEC16: every tile starts on a 16-byte boundary in global memory and b0 is a multiple of 64 boards
+template <u32 BOARDS, bool VEC16 = false>
 __device__ inline void obs_wave_copy_out(uint8_t *lds, const ObsOut &o, int64_t first, u32 b0, u32 b1) {
-    wave_copy_out(reinterpret_cast<uint8_t *>(o.classical) + first * 9, lds, b0 * 9u, b1 * 9u);
+#define QTTT_WCO(G, ROW) do { if (VEC16) wave_copy_out16(G, lds, b0 * (ROW), b1 * (ROW)); else wave_copy_out(G, lds, b0 * (ROW), b1 * (ROW)); } while (0)
+    QTTT_WCO(reinterpret_cast<uint8_t *>(o.classical) + first * 9, 9u);
     lds += obs_tile_bytes(BOARDS, 9);
-    wave_copy_out(o.q_p1 + first * 10, lds, b0 * 10u, b1 * 10u);
+    QTTT_WCO(o.q_p1 + first * 10, 10u);
     lds += obs_tile_bytes(BOARDS, 10);
-    wave_copy_out(o.q_p2 + first * 8, lds, b0 * 8u, b1 * 8u);
+    QTTT_WCO(o.q_p2 + first * 8, 8u);
     lds += obs_tile_bytes(BOARDS, 8);
-    wave_copy_out(o.q_p1_len + first, lds, b0, b1);
+    QTTT_WCO(o.q_p1_len + first, 1u);
     lds += obs_tile_bytes(BOARDS, 1);
-    wave_copy_out(o.q_p2_len + first, lds, b0, b1);
+    QTTT_WCO(o.q_p2_len + first, 1u);
     lds += obs_tile_bytes(BOARDS, 1);
-    wave_copy_out(o.turn + first, lds, b0, b1);
+    QTTT_WCO(o.turn + first, 1u);
+#undef QTTT_WCO
 }
 
 template <u32 BOARDS>
@@ -187,15 +206,10 @@ __device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles
     const u32 o03 = (c03 ^ 0x0F0F0F0Fu) | ~m03;
     const u32 o47 = (c47 ^ 0x0F0F0F0Fu) | ~m47;
     const u32 o8 = (cl & 0x100u) ? (c8 ^ 0xFu) : 0xFFu;
+    // a 9-byte row: one 8-byte and one 1-byte LDS store (gfx950 does unaligned DS accesses)
     uint8_t *rc = T.cl + b * 9u;
-    rc[0] = (uint8_t)o03;
-    rc[1] = (uint8_t)(o03 >> 8);
-    rc[2] = (uint8_t)(o03 >> 16);
-    rc[3] = (uint8_t)(o03 >> 24);
-    rc[4] = (uint8_t)o47;
-    rc[5] = (uint8_t)(o47 >> 8);
-    rc[6] = (uint8_t)(o47 >> 16);
-    rc[7] = (uint8_t)(o47 >> 24);
+    const u64 o07 = (u64)o03 | ((u64)o47 << 32);
+    __builtin_memcpy(rc, &o07, 8);
     rc[8] = (uint8_t)o8;
     // ---- holders by code: four times the code of a square that holds a live edge (0 otherwise)
     const u32 S03 = (c03 & ~m03) << 2, S47 = (c47 & ~m47) << 2, S8 = (cl & 0x100u) ? 0u : c8 << 2;

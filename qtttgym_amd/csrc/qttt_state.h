@@ -201,6 +201,27 @@ __device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32
     return policy_nth(plut, empty, c5, ij & 0xFu) | (policy_nth(plut, empty, c5, ij >> 4) << 8);
 }
 
+// nth9[m * 9 + r] = the r-th empty square of the 9-bit mask m: kernels that run the policy for many plies per
+// board (rollout, fused random stepping) use this full table (4.5 KB, computed here: thread m writes row m)
+// instead of the two-level lookup of policy_nth()
+template <int BLOCK>
+__device__ inline void fill_nth9(uint8_t *nth9) {
+    for (u32 m = threadIdx.x; m < 512u; m += BLOCK) {
+        u32 r = 0;
+#pragma unroll
+        for (u32 v = 0; v < 9; ++v) {
+            nth9[m * 9u + r] = (uint8_t)v;                 // kept only if bit v is set (r advances), else overwritten
+            r += m >> v & 1u;                              // r <= v inside the loop: the store stays in row m
+        }
+    }
+}
+// the policy's action for the empty-square mask `empty` (>= 2 squares) from hash word h2: lo | hi << 8
+__device__ __forceinline__ u32 policy_action_nth9(const uint8_t *plut, const uint8_t *nth9, u32 empty, u32 h2) {
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 ij = plut[e * 36u + __umulhi(h2, (e * (e - 1u)) >> 1)];
+    return (u32)nth9[empty * 9u + (ij & 0xFu)] | ((u32)nth9[empty * 9u + (ij >> 4)] << 8);
+}
+
 }  // namespace
 
 #endif  // QTTT_STATE_H

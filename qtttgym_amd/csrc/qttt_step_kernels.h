@@ -1,5 +1,6 @@
-// qttt_step_kernels.h — the step kernels: lane per board (the product), wave per board (mapping study),
-// and the T-steps-in-registers replay form.
+// qttt_step_kernels.h — the step kernels: lane per board, one launch per step (the metric's form), and the
+// T-steps-in-registers forms (recorded actions / in-kernel policy).  The wave-per-board mapping study
+// lives in tools/qttt_study.hip, outside the product library.
 #ifndef QTTT_STEP_KERNELS_H
 #define QTTT_STEP_KERNELS_H
 #include "qttt_step_core.h"
@@ -18,7 +19,7 @@ namespace {
 // BLOCK, BPL: workgroup size and boards per lane, chosen by the host per launch from the batch size
 // (auto_tuning() in qttt_kernels.hip holds the measured table: one board per lane in 256-thread
 // workgroups below ~450 K boards, 1024-thread workgroups where they fill the chip exactly once,
-// two boards per lane in 256-thread workgroups from 2 M boards up).
+// two boards per lane in 256-thread workgroups above 1 536 K boards).
 template <int BLOCK, int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, uint16_t *__restrict__ actions,
@@ -104,11 +105,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     }
     if (OBS) {
         // a wave's boards [64w * BPL, 64(w+1) * BPL) start on a multiple of 4 bytes in every tile
-        if ((64u * BPL) % 4u == 0u && obs_all_phase0(obs, ib)) {
+        const u32 ph = obs_all_phases(obs, ib, 15u);                 // block-uniform
+        if ((ph & 3u) == 0u) {
             const u32 w0 = (threadIdx.x & ~63u) * BPL;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // rows written by other lanes of this wave
             __builtin_amdgcn_wave_barrier();
-            if (w0 < ng * BPL) obs_wave_copy_out<TILE_BOARDS>(otile, obs, ib, w0, min(w0 + 64u * BPL, ng * BPL));
+            if (w0 < ng * BPL) {
+                if (ph == 0u) obs_wave_copy_out<TILE_BOARDS, true>(otile, obs, ib, w0, min(w0 + 64u * BPL, ng * BPL));
+                else obs_wave_copy_out<TILE_BOARDS, false>(otile, obs, ib, w0, min(w0 + 64u * BPL, ng * BPL));
+            }
         } else {
             __syncthreads();
             obs_copy_out<BLOCK, TILE_BOARDS>(otile, obs, ib, ng * BPL);
@@ -123,42 +128,6 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
     }
 #endif
-}
-
-// Mapping study: ONE WAVEFRONT PER BOARD, the mapping BASELINE.json's north_star
-// sketches.  A board's step is a chain of dependent operations on a 9-node graph (validity ->
-// component lookup -> path walk -> collapse -> line test), so whatever the 64 lanes of a wave do
-// with __shfl/__ballot, the wave cannot retire a board faster than one lane can run that chain.
-// This kernel is that lower bound made concrete: lane 0 of every wave runs the same step_core, the
-// other 63 lanes are idle, state is staged through LDS by the workgroup.  Same results as
-// step_kernel (tested); measured beside it in tools/stepbench.
-template <bool HAS_BITS, bool AUTO_RESET>
-__global__ __launch_bounds__(256) void step_wave_per_board_kernel(
-    u64 *__restrict__ pP, u64 *__restrict__ pQ, const uint16_t *__restrict__ actions,
-    const uint8_t *__restrict__ bits, u32 key_fold, u32 id_base, u32 *__restrict__ reward_bits,
-    uint8_t *__restrict__ terminated, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    __shared__ u64 sP[4], sQ[4];
-    __shared__ u32 sAct[4], sBit[4];
-    fill_line_lut_nosync<256>(lut);
-    const int64_t i0 = (int64_t)blockIdx.x * 4;                   // 4 waves = 4 boards per workgroup
-    if (threadIdx.x < 4 && i0 + threadIdx.x < n) {                 // cooperative tile load into LDS
-        const int64_t i = i0 + threadIdx.x;
-        sP[threadIdx.x] = pP[i];
-        sQ[threadIdx.x] = pQ[i];
-        sAct[threadIdx.x] = actions[i];
-        sBit[threadIdx.x] = HAS_BITS ? bits[i] & 1u : collapse_bit_of((id_base + (u32)i) ^ key_fold);
-    }
-    __syncthreads();
-    const u32 w = threadIdx.x >> 6;
-    const int64_t i = i0 + w;
-    if (i >= n || (threadIdx.x & 63u) != 0u) return;              // lane 0 of each wave owns the board
-    u32 P0 = (u32)sP[w], P1 = (u32)(sP[w] >> 32), Q0 = (u32)sQ[w], Q1 = (u32)(sQ[w] >> 32);
-    const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, sAct[w], sBit[w], lut);
-    pP[i] = (u64)P0 | ((u64)P1 << 32);
-    pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
-    reward_bits[i] = 0x80000000u | (win << 23);
-    terminated[i] = (uint8_t)(P1 >> 31);
 }
 
 // T consecutive steps in ONE launch (qttt_step_many with QTTT_FLAG_FUSED): the boards stay in
@@ -195,6 +164,66 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
     }
     pP[i] = (u64)P0 | ((u64)P1 << 32);
     pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
+}
+
+// The same with the uniform-legal policy IN the kernel (qttt_step_random_many): T consecutive
+// qttt_step_random steps — policy -> collapse bit -> step, ply t keyed by the counter hash of
+// (seed, global board id, step_idx0 + t) exactly as the launch-by-launch form — with the boards in
+// registers.  This is MCTS._simulate's loop (mcts.py:185-198: policy -> step until terminal) turned
+// into the env's throughput mode: with AUTO_RESET a finished board restarts on its next ply, so every
+// ply of every lane is a live transition.  Per ply it moves only what the caller keeps (nothing, or
+// action 2 B + reward 4 B + terminated 1 B per board), so it is VALU-bound and pays one launch per T
+// steps: this is what takes batches of <= 512 K boards (BASELINE configs 2-4: one partial occupancy
+// round per launch) out of the launch-bound regime.
+//   nth9 / policy_action_nth9: qttt_state.h (the full 4.5 KB "r-th empty square" table, computed by the workgroup).
+// With AUTO_RESET the policy always has a legal pair (a board that is not done has >= 2 empty squares:
+// 8 classical squares set the done bit), so the step runs TRUSTED (no validation, no sorting).
+template <int BLOCK, bool AUTO_RESET>
+__global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, u64 seed, u32 step_idx0, u64 board_offset,
+    uint16_t *__restrict__ actions_out, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    int64_t out_stride, int64_t n, int32_t n_steps) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    __shared__ uint8_t nth9[512 * 9];
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < n;
+    const int64_t il = active ? i : 0;                              // idle lanes re-read board 0, store nothing
+    const u64 P = load_stream(&pP[il]), Q = load_stream(&pQ[il]);   // requested before the table fills
+    fill_policy_lut<BLOCK>(plut);
+    fill_nth9<BLOCK>(nth9);
+    fill_line_lut<BLOCK>(lut);                                      // ends with the workgroup barrier
+    if (!active) return;
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
+    const u32 id = fold_id(board_offset + (u64)i);
+    for (int32_t t = 0; t < n_steps; ++t) {
+        const u64 key = launch_key(seed, step_idx0 + (u32)t);       // wave-uniform: scalar unit
+        const u32 h1 = lowbias32(id ^ (u32)key);
+        const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+        u32 act, win;
+        if (AUTO_RESET) {
+            const u32 keep = ~(u32)((int)P1 >> 31);                 // a finished board restarts: empty = all zero
+            P0 &= keep; P1 &= keep; Q0 &= keep; Q1 &= keep;
+            const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;        // >= 2 squares: the board is not done
+            act = policy_action_nth9(plut, nth9, empty, h2);
+            win = step_core<false, true>(P0, P1, Q0, Q1, act, h1 >> 31, lut);
+        } else {
+            // post-terminal legal moves are accepted; no legal pair -> (0,0), a noop
+            const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
+            act = (empty & (empty - 1u)) ? policy_action_nth9(plut, nth9, empty, h2) : 0u;
+            win = step_core<false, false>(P0, P1, Q0, Q1, act, h1 >> 31, lut);
+        }
+        if (out_stride != 0 || t == n_steps - 1) {
+            const int64_t o = (int64_t)t * out_stride + i;
+            if (actions_out) store_stream(&actions_out[o], (uint16_t)act);
+            if (reward_bits) {
+                store_stream(&reward_bits[o], 0x80000000u | (win << 23));     // env.py:49: -1.0f / -0.0f
+                store_stream(&terminated[o], (uint8_t)(P1 >> 31));            // env.py:51
+            }
+        }
+    }
+    store_stream(&pP[i], (u64)P0 | ((u64)P1 << 32));
+    store_stream(&pQ[i], (u64)Q0 | ((u64)Q1 << 32));
 }
 
 }  // namespace

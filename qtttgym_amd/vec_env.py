@@ -23,8 +23,18 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _check_out(t, dtype, shape, dev, what):
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != dev:
+        raise ValueError("%s must be a contiguous %s device tensor of shape %s" % (what, dtype, tuple(shape)))
+    return t
+
+
 class VecEnv:
-    def __init__(self, num_envs, device="cuda", seed=0, auto_reset=False, board_offset=0):
+    """Thread-safety: the C library may be called from any number of host threads at once; ONE VecEnv
+    (its state, its output buffers and its qttt_env record) belongs to one thread at a time, exactly
+    like the reference's mutable Env (env.py:15)."""
+
+    def __init__(self, num_envs, device="cuda", seed=0, auto_reset=False, board_offset=0, launch_shape=None):
         self.num_envs = int(num_envs)
         if self.num_envs < 0:
             raise ValueError("num_envs must be >= 0")
@@ -42,6 +52,9 @@ class VecEnv:
         self.auto_reset = bool(auto_reset)
         self.board_offset = int(board_offset)     # global index of board 0 (multi-GPU shards)
         self.step_idx = 0
+        # (boards per lane, workgroup size) of this environment's step launches, carried by every call's
+        # flags (QTTT_FLAG_SHAPE); None = the library picks it from the batch size.  Never changes results.
+        self._shape_flags = _native.flag_shape(*launch_shape) if launch_shape else 0
         self.action_space = reference_action_space()
         self.observation_space = reference_observation_space()
         n = self.num_envs
@@ -87,7 +100,7 @@ class VecEnv:
         return _raw_stream(self._dev_index)
 
     def _flags(self):
-        return _native.FLAG_AUTO_RESET if self.auto_reset else 0
+        return (_native.FLAG_AUTO_RESET if self.auto_reset else 0) | self._shape_flags
 
     def _as_actions(self, actions):
         if not torch.is_tensor(actions):
@@ -182,17 +195,23 @@ class VecEnv:
         self.step_idx += T
         return r, tm
 
-    def step(self, actions, bits=None, verbose=False):
+    def step(self, actions, bits=None, verbose=False, copy_obs=True):
         """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info) from ONE kernel
-        launch (the step kernel writes the observation from the registers it holds).  The returned
-        tensors are the environment's own buffers, overwritten by the next step()/observ()."""
-        if not (torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == self.state.device
-                and actions.shape == (self.num_envs, 2)):         # (step_observe_raw checks the layout)
+        launch (the step kernel writes the observation from the registers it holds).
+        copy_obs=True (default): the returned observation, reward and terminated are fresh tensors, as a
+        gym caller that keeps (obs, next_obs) pairs expects.  copy_obs=False returns the environment's
+        own buffers, overwritten by the next step()/observ() — the zero-copy form, = step_observe_raw."""
+        dev = self.state.device
+        if not (torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == dev
+                and actions.shape == (self.num_envs, 2) and actions.is_contiguous()):
             actions = self._as_actions(actions)
-        if bits is not None and not (torch.is_tensor(bits) and bits.dtype == torch.uint8
-                                     and bits.device == self.state.device):
+        if bits is not None and not (torch.is_tensor(bits) and bits.dtype == torch.uint8 and bits.device == dev
+                                     and bits.is_contiguous()):
             bits = torch.as_tensor(bits).to(torch.uint8).to(self.device).contiguous()
         obs, reward, terminated = self.step_observe_raw(actions, bits)
+        if copy_obs:
+            obs = {k: v.clone() for k, v in obs.items()}
+            reward, terminated = reward.clone(), terminated.clone()
         return obs, reward, terminated, self._truncated, {}
 
     def _obs_buffers(self):
@@ -248,9 +267,19 @@ class VecEnv:
         _native.check(rc, "qttt_observe")
         return obs
 
-    def turn(self):
-        """env.py:65-66: len(moves) per board (counts the autofill move)."""
-        return self.export_boards()["n_moves"]
+    def turn(self, out=None):
+        """env.py:65-66: len(moves) per board (counts the autofill move), u8[N]: qttt_export asked for
+        n_moves alone (8 bytes read and 1 written per board).  `out` = a tensor to overwrite."""
+        n = self.num_envs
+        if out is None:
+            with torch.cuda.device(self.device):
+                out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        else:
+            _check_out(out, torch.uint8, (n,), self.state.device, "out")
+        rc = self._launch(self._lib.qttt_export, self.state.data_ptr(), None, out.data_ptr(), None, None, None, n,
+                          self._stream())
+        _native.check(rc, "qttt_export")
+        return out
 
     def render(self, index=0):
         from .board import Board, displayBoard
@@ -274,21 +303,22 @@ class VecEnv:
         _native.check(rc, "qttt_check_win")
         return p1, p2
 
-    def export_boards(self):
-        """Board.moves / .board / .qstructs (board.py:4-6) as tensors."""
-        n = self.num_envs
-        dev = self.device
-        with torch.cuda.device(dev):
-            out = {
-                "moves": torch.empty((n, 9, 2), dtype=torch.uint8, device=dev),
-                "n_moves": torch.empty(n, dtype=torch.uint8, device=dev),
-                "board": torch.empty((n, 9), dtype=torch.int8, device=dev),
-                "qmask": torch.empty((n, 4), dtype=torch.int16, device=dev),
-                "n_q": torch.empty(n, dtype=torch.uint8, device=dev),
-            }
-            rc = self._lib.qttt_export(self.state.data_ptr(), out["moves"].data_ptr(),
-                                       out["n_moves"].data_ptr(), out["board"].data_ptr(),
-                                       out["qmask"].data_ptr(), out["n_q"].data_ptr(), n, self._stream())
+    _EXPORT_SPEC = (("moves", torch.uint8, (9, 2)), ("n_moves", torch.uint8, ()), ("board", torch.int8, (9,)),
+                    ("qmask", torch.int16, (4,)), ("n_q", torch.uint8, ()))
+
+    def export_boards(self, out=None):
+        """Board.moves / .board / .qstructs (board.py:4-6) as tensors.  `out` = the dict of an earlier
+        call, to be overwritten instead of allocating."""
+        n, dev = self.num_envs, self.device
+        if out is None:
+            with torch.cuda.device(dev):
+                out = {k: torch.empty((n,) + shp, dtype=dt, device=dev) for k, dt, shp in self._EXPORT_SPEC}
+        else:
+            for k, dt, shp in self._EXPORT_SPEC:
+                _check_out(out[k], dt, (n,) + shp, self.state.device, "out[%r]" % k)
+        rc = self._launch(self._lib.qttt_export, self.state.data_ptr(), out["moves"].data_ptr(),
+                          out["n_moves"].data_ptr(), out["board"].data_ptr(), out["qmask"].data_ptr(),
+                          out["n_q"].data_ptr(), n, self._stream())
         _native.check(rc, "qttt_export")
         return out
 
@@ -312,16 +342,41 @@ class VecEnv:
         _native.check(rc, "qttt_import")
 
     def sample_actions(self, out=None):
-        """Uniform-legal synthetic policy for the *next* step."""
+        """Uniform-legal synthetic policy for the *next* step.  `out` u8[N,2] to overwrite."""
         n = self.num_envs
-        with torch.cuda.device(self.device):
-            if out is None:
+        if out is None:
+            with torch.cuda.device(self.device):
                 out = torch.empty((n, 2), dtype=torch.uint8, device=self.device)
-            rc = self._lib.qttt_sample_actions(self.state.data_ptr(), self.seed, self.step_idx,
-                                               self.board_offset, self._flags(), out.data_ptr(), n,
-                                               self._stream())
+        elif out.dtype != torch.uint8 or out.numel() != 2 * n or not out.is_contiguous() or out.device != self.state.device:
+            raise ValueError("out must be a contiguous uint8 device tensor of shape (N, 2)")
+        rc = self._launch(self._lib.qttt_sample_actions, self.state.data_ptr(), self.seed, self.step_idx,
+                          self.board_offset, self._flags(), out.data_ptr(), n, self._stream())
         _native.check(rc, "qttt_sample_actions")
         return out
+
+    def step_random_many(self, n_steps, actions_out=None, reward=None, terminated=None):
+        """n_steps steps under the in-kernel uniform-legal policy in ONE launch with the boards in
+        registers (qttt_step_random_many) == n_steps calls of step_random().  With reward f32[T,N] +
+        terminated bool[T,N] (and optionally actions_out u8[T,N,2]) every step's outputs are kept; without
+        them only the last step's are written (to the environment's own reward / terminated buffers, which
+        are returned; actions_out u8[N,2] optional)."""
+        n, T, dev = self.num_envs, int(n_steps), self.state.device
+        keep = reward is not None or terminated is not None
+        stride = 0
+        r, tm = self._reward, self._terminated
+        if keep:
+            if reward is None or terminated is None:
+                raise ValueError("reward f32[T,N] and terminated bool[T,N] must be given together")
+            r, tm = _check_out(reward, torch.float32, (T, n), dev, "reward"), _check_out(terminated, torch.bool, (T, n), dev, "terminated")
+            stride = n
+        if actions_out is not None:        # one out_stride for all outputs: [T,N,2] with reward/terminated [T,N], else [N,2]
+            _check_out(actions_out, torch.uint8, (T, n, 2) if keep else (n, 2), dev, "actions_out")
+        rc = self._launch(self._lib.qttt_step_random_many, self.state.data_ptr(), self.seed, self.step_idx,
+                          self.board_offset, self._flags(), _ptr(actions_out), r.data_ptr(), tm.data_ptr(), stride, n, T,
+                          self._stream())
+        _native.check(rc, "qttt_step_random_many")
+        self.step_idx += T
+        return r, tm
 
     # ------------------------------------------------------------------ MCTS-side rows (SURVEY §8f)
     @classmethod
@@ -334,6 +389,7 @@ class VecEnv:
         if state.dtype != torch.uint8 or state.numel() != env._lib.qttt_state_bytes(env.num_envs):
             raise ValueError("state must be a uint8 tensor of qttt_state_bytes(num_envs) bytes")
         env.seed, env.auto_reset, env.board_offset, env.step_idx = int(seed), bool(auto_reset), int(board_offset), 0
+        env._shape_flags = 0
         env.action_space = reference_action_space()
         env.observation_space = reference_observation_space()
         env.state = state
@@ -368,55 +424,83 @@ class VecEnv:
         _native.check(rc, "qttt_node_info")
         return out
 
-    def expand(self, action36):
+    def expand(self, action36, out=None):
         """MCTS._step (mcts.py:233-267) for every board: action36 u8[N] (ind2move index).
         Returns dict(child0, child1 = VecEnv over the child states, n_children u8[N],
-        winner i8[N,2], terminal bool[N,2], legal int64[N,2], key int64[N,2])."""
+        winner i8[N,2], terminal bool[N,2], legal int64[N,2], key int64[N,2]).
+        `out` = the dict of an earlier call: its child states and tensors are overwritten (a search loop
+        then allocates nothing per expansion)."""
         n, dev = self.num_envs, self.device
-        a = torch.as_tensor(action36).to(torch.uint8).to(dev).contiguous()
+        a = action36
+        if not (torch.is_tensor(a) and a.dtype == torch.uint8 and a.device == self.state.device and a.is_contiguous()):
+            a = torch.as_tensor(a).to(torch.uint8).to(dev).contiguous()
         if a.shape != (n,):
             raise ValueError("action36 must have shape (%d,)" % n)
-        with torch.cuda.device(dev):
-            c0 = torch.empty_like(self.state)
-            c1 = torch.empty_like(self.state)
-            nch = torch.empty(n, dtype=torch.uint8, device=dev)
-            winner = torch.empty((n, 2), dtype=torch.int8, device=dev)
-            terminal = torch.empty((n, 2), dtype=torch.bool, device=dev)
-            legal = torch.empty((n, 2), dtype=torch.int64, device=dev)
-            key = torch.empty((n, 2), dtype=torch.int64, device=dev)
-            rc = self._lib.qttt_expand(self.state.data_ptr(), a.data_ptr(), c0.data_ptr(), c1.data_ptr(),
-                                       nch.data_ptr(), winner.data_ptr(), terminal.data_ptr(),
-                                       legal.data_ptr(), key.data_ptr(), n, self._stream())
+        if out is None:
+            with torch.cuda.device(dev):
+                mk = lambda: VecEnv.from_state(torch.empty_like(self.state), n, seed=self.seed, board_offset=self.board_offset)
+                out = {"child0": mk(), "child1": mk(),
+                       "n_children": torch.empty(n, dtype=torch.uint8, device=dev),
+                       "winner": torch.empty((n, 2), dtype=torch.int8, device=dev),
+                       "terminal": torch.empty((n, 2), dtype=torch.bool, device=dev),
+                       "legal": torch.empty((n, 2), dtype=torch.int64, device=dev),
+                       "key": torch.empty((n, 2), dtype=torch.int64, device=dev)}
+        else:
+            sd = self.state.device
+            for c in ("child0", "child1"):
+                if out[c].num_envs != n or out[c].state.device != sd:
+                    raise ValueError("out[%r] must be a VecEnv of N boards on this device" % c)
+            _check_out(out["n_children"], torch.uint8, (n,), sd, "out['n_children']")
+            _check_out(out["winner"], torch.int8, (n, 2), sd, "out['winner']")
+            _check_out(out["terminal"], torch.bool, (n, 2), sd, "out['terminal']")
+            _check_out(out["legal"], torch.int64, (n, 2), sd, "out['legal']")
+            _check_out(out["key"], torch.int64, (n, 2), sd, "out['key']")
+        rc = self._launch(self._lib.qttt_expand, self.state.data_ptr(), a.data_ptr(), out["child0"].state.data_ptr(),
+                          out["child1"].state.data_ptr(), out["n_children"].data_ptr(), out["winner"].data_ptr(),
+                          out["terminal"].data_ptr(), out["legal"].data_ptr(), out["key"].data_ptr(), n, self._stream())
         _native.check(rc, "qttt_expand")
-        mk = lambda st: VecEnv.from_state(st, n, seed=self.seed, board_offset=self.board_offset)
-        return {"child0": mk(c0), "child1": mk(c1), "n_children": nch, "winner": winner,
-                "terminal": terminal, "legal": legal, "key": key}
+        return out
 
-    def rollout(self, step_idx0=None, return_final=False):
+    def rollout(self, step_idx0=None, return_final=False, out=None):
         """MCTS._simulate (mcts.py:185-198) under uniform priors: one fused random playout per
-        board, boards unchanged.  Returns (result i8[N] in {+1,-1,0}, plies u8[N][, final VecEnv])."""
+        board, boards unchanged.  Returns (result i8[N] in {+1,-1,0}, plies u8[N][, final VecEnv]).
+        `out` = the tuple of an earlier call with the same return_final, to be overwritten."""
         n, dev = self.num_envs, self.device
         if step_idx0 is None:
             step_idx0 = self.step_idx
-        with torch.cuda.device(dev):
-            result = torch.empty(n, dtype=torch.int8, device=dev)
-            plies = torch.empty(n, dtype=torch.uint8, device=dev)
-            final = torch.empty_like(self.state) if return_final else None
-            rc = self._lib.qttt_rollout(self.state.data_ptr(), self.seed, int(step_idx0), self.board_offset,
-                                        result.data_ptr(), plies.data_ptr(), _ptr(final), n, self._stream())
+        if out is None:
+            with torch.cuda.device(dev):
+                result = torch.empty(n, dtype=torch.int8, device=dev)
+                plies = torch.empty(n, dtype=torch.uint8, device=dev)
+                final = (VecEnv.from_state(torch.empty_like(self.state), n, seed=self.seed, board_offset=self.board_offset)
+                         if return_final else None)
+        else:
+            result, plies = out[0], out[1]
+            final = out[2] if return_final else None
+            _check_out(result, torch.int8, (n,), self.state.device, "out[0]")
+            _check_out(plies, torch.uint8, (n,), self.state.device, "out[1]")
+            if return_final and (final.num_envs != n or final.state.device != self.state.device):
+                raise ValueError("out[2] must be a VecEnv of N boards on this device")
+        rc = self._launch(self._lib.qttt_rollout, self.state.data_ptr(), self.seed, int(step_idx0), self.board_offset,
+                          result.data_ptr(), plies.data_ptr(), None if final is None else final.state.data_ptr(), n,
+                          self._stream())
         _native.check(rc, "qttt_rollout")
-        if return_final:
-            return result, plies, VecEnv.from_state(final, n, seed=self.seed, board_offset=self.board_offset)
-        return result, plies
+        return (result, plies, final) if return_final else (result, plies)
 
-    def encode(self, with_mask=True):
+    def encode(self, with_mask=True, out=None):
         """GameState.to_vector (mcts.py:67-85) as f32[N,18,10] and action_mask (mcts.py:87-91) as
-        bool[N,36], without leaving the GPU."""
+        bool[N,36], without leaving the GPU.  `out` = what an earlier call returned, to be overwritten."""
         n, dev = self.num_envs, self.device
-        with torch.cuda.device(dev):
-            vec = torch.empty((n, 18, 10), dtype=torch.float32, device=dev)
-            mask = torch.empty((n, 36), dtype=torch.bool, device=dev) if with_mask else None
-            rc = self._lib.qttt_encode(self.state.data_ptr(), vec.data_ptr(), _ptr(mask), n, self._stream())
+        if out is None:
+            with torch.cuda.device(dev):
+                vec = torch.empty((n, 18, 10), dtype=torch.float32, device=dev)
+                mask = torch.empty((n, 36), dtype=torch.bool, device=dev) if with_mask else None
+        else:
+            vec, mask = (out if with_mask else (out, None))
+            _check_out(vec, torch.float32, (n, 18, 10), self.state.device, "out vec")
+            if with_mask:
+                _check_out(mask, torch.bool, (n, 36), self.state.device, "out mask")
+        rc = self._launch(self._lib.qttt_encode, self.state.data_ptr(), vec.data_ptr(), _ptr(mask), n, self._stream())
         _native.check(rc, "qttt_encode")
         return (vec, mask) if with_mask else vec
 

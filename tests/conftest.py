@@ -19,6 +19,7 @@ def pytest_sessionstart(session):
     try:
         import __graft_entry__ as g
         g.build_hip()
+        g.build_study()
     except Exception as e:                                    # noqa: BLE001
         sys.stderr.write("conftest: could not build libqttt_hip.so: %s\n" % e)
 

@@ -89,8 +89,20 @@ def test_launch_shape_table_and_overrides():
         for n, shape in expect.items():
             assert _native.step_launch_shape(n) == shape, n
         assert L.qttt_set_tuning(4, 1024) == 0 and _native.step_launch_shape(1 << 20) == (4, 512)   # 4 per lane: 512 only
-        assert L.qttt_set_tuning(2, 0) == 0 and _native.step_launch_shape(1 << 20) == (2, 512)
+        assert _native.step_launch_shape(1 << 20, observe=True) == (2, 1024)    # the observation tiles take <= 2 per lane
+        # only boards-per-lane given: the workgroup size stays the table's choice for the batch
+        assert L.qttt_set_tuning(2, 0) == 0 and _native.step_launch_shape(1 << 20) == (2, 1024)
+        assert _native.step_launch_shape(262144) == (2, 256)
+        assert L.qttt_set_tuning(1, 0) == 0 and _native.step_launch_shape(1 << 20) == (1, 1024)
         assert L.qttt_set_tuning(0, 256) == 0 and _native.step_launch_shape(1 << 20) == (2, 256)
+        # a call's own QTTT_FLAG_SHAPE bits win over the process-wide default
+        assert _native.step_launch_shape(1 << 20, _native.flag_shape(1, 512)) == (1, 512)
+        assert _native.step_launch_shape(1 << 20, _native.flag_shape(4, 0)) == (4, 512)
+        assert _native.step_launch_shape(1 << 20, _native.flag_shape(4, 0), observe=True) == (2, 1024)
+        assert _native.step_launch_shape(1 << 20, 1) == (2, 256)                 # AUTO_RESET alone: no shape bits
+        assert L.qttt_set_tuning(0, 0) == 0
+        assert _native.step_launch_shape(4096, _native.flag_shape(0, 1024)) == (1, 1024)
+        assert _native.flag_shape(2, 1024) == (2 << 8) | (3 << 12) and _native.flag_shape() == 0
         for bad in ((3, 0), (8, 0), (-1, 0), (2, 128), (2, 2048), (0, -256)):
             assert L.qttt_set_tuning(*bad) == -2
         with pytest.raises(RuntimeError):

@@ -54,7 +54,8 @@ def test_every_launch_shape_vs_oracle(tuning, bpl, blk, n):
     assert tuning(3, 0) != 0 and tuning(2, 128) != 0 and tuning(-1, 0) != 0
     shape = _native.step_launch_shape(n)
     if bpl:
-        assert shape == (bpl, 512 if bpl == 4 else (blk or 512))
+        auto_blk = 256 if n <= 448 * 1024 else 1024
+        assert shape == (bpl, 512 if bpl == 4 else (blk or auto_blk))
     else:
         assert shape == ((1, 256) if n <= 448 * 1024 else (2, 1024))
     for auto_reset in (False, True):

@@ -1,0 +1,349 @@
+"""Round 3 on the GPU, through the C ABI:
+  * qttt_step_random_many — T steps of the in-kernel uniform-legal policy in one launch — against the
+    oracle's sample_actions/step loop (the policy -> step loop of mcts.py:185-198 over env.py:34-53),
+  * the launch shape carried per call (QTTT_FLAG_SHAPE) from two host threads at once,
+  * qttt_export through LDS tiles with every output nullable (Env.turn = n_moves alone, env.py:65-66),
+  * two boards per lane in qttt_node_info / paired children in qttt_expand at ragged sizes,
+  * the out= forms of the rows a search loop calls, VecEnv.step's copies and non-contiguous inputs."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _assert_same_as_oracle(env, ob, tag="", sel=slice(None)):
+    ex = {k: _np(v) for k, v in env.export_boards().items()}
+    assert np.array_equal(ex["board"][sel], ob.board[sel]), tag
+    assert np.array_equal(ex["n_moves"][sel], ob.n_moves[sel]), tag
+    assert np.array_equal(ex["moves"][sel], ob.moves[sel]), tag
+    assert np.array_equal(ex["n_q"][sel], ob.n_q[sel]), tag
+    assert np.array_equal(ex["qmask"].view(np.uint16)[sel], ob.qmask[sel]), tag
+
+
+def _oracle_random_steps(n, T, seed, off, auto_reset, step_idx0=0):
+    ob = oracle.OracleBoards(n)
+    acts = np.empty((T, n, 2), dtype=np.uint8)
+    rew = np.empty((T, n), dtype=np.uint32)
+    term = np.empty((T, n), dtype=np.uint8)
+    for t in range(T):
+        acts[t] = ob.sample_actions(seed, step_idx0 + t, off, auto_reset)
+        r, tm = ob.step(acts[t], None, seed, step_idx0 + t, off, auto_reset)
+        rew[t], term[t] = r.view(np.uint32), tm
+    return ob, acts, rew, term
+
+
+@pytest.mark.parametrize("n,T", [(1, 1), (1, 9), (1, 64), (4096, 1), (4096, 9), (4096, 64), (262144, 9),
+                                 (262144, 64), (1048577, 9)])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_step_random_many_every_output_kept_vs_oracle(n, T, auto_reset):
+    from qtttgym_amd import VecEnv
+    if n == 262144 and T == 64 and not auto_reset:
+        pytest.skip("covered by the auto-reset case; keeps the suite short")
+    seed, off = 4242 + n + T, 3 * n
+    ob, acts, rew, term = _oracle_random_steps(n, T, seed, off, auto_reset)
+    env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    a = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+    r = torch.empty((T, n), dtype=torch.float32, device="cuda")
+    tm = torch.empty((T, n), dtype=torch.bool, device="cuda")
+    got_r, got_t = env.step_random_many(T, actions_out=a, reward=r, terminated=tm)
+    assert got_r is r and got_t is tm and env.step_idx == T
+    assert np.array_equal(_np(a), acts)
+    assert np.array_equal(_np(r).view(np.uint32), rew)
+    assert np.array_equal(_np(tm).astype(np.uint8), term)
+    _assert_same_as_oracle(env, ob, (n, T, auto_reset))
+
+
+@pytest.mark.parametrize("n,T,off", [(4099, 13, 0), (5000, 9, (1 << 32) - 2500), (70000, 20, (1 << 40) + 5)])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_step_random_many_last_only_in_two_chunks_and_across_2_pow_32(n, T, off, auto_reset):
+    """Only the last step's outputs are written (out_stride 0); two launches of T1 + T2 steps continue the
+    step counter; board ids cross 2^32 inside the batch."""
+    from qtttgym_amd import VecEnv
+    seed = 99
+    T1 = T // 2
+    ob, acts, rew, term = _oracle_random_steps(n, T, seed, off, auto_reset)
+    env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    last_a = torch.zeros((n, 2), dtype=torch.uint8, device="cuda")
+    env.step_random_many(T1)
+    r, tm = env.step_random_many(T - T1, actions_out=last_a)
+    assert r is env._reward and env.step_idx == T
+    assert np.array_equal(_np(last_a), acts[-1])
+    assert np.array_equal(_np(r).view(np.uint32), rew[-1])
+    assert np.array_equal(_np(tm).astype(np.uint8), term[-1])
+    _assert_same_as_oracle(env, ob, (n, T, off))
+
+
+def test_step_random_many_equals_step_random_launch_by_launch():
+    """The fused form is bit-identical to T calls of step_random (policy + step fused in one kernel per step)."""
+    from qtttgym_amd import VecEnv
+    n, T, seed = 300001, 24, 5
+    a, b = VecEnv(n, seed=seed, auto_reset=True), VecEnv(n, seed=seed, auto_reset=True)
+    ra = torch.empty((T, n), dtype=torch.float32, device="cuda")
+    ta = torch.empty((T, n), dtype=torch.bool, device="cuda")
+    aa = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+    a.step_random_many(T, actions_out=aa, reward=ra, terminated=ta)
+    act = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        r, tm = b.step_random(actions_out=act)
+        assert torch.equal(act, aa[t]), t
+        assert torch.equal(r.view(torch.int32), ra[t].view(torch.int32)) and torch.equal(tm, ta[t]), t
+    assert torch.equal(a.state, b.state)
+
+
+def test_step_random_many_argument_errors():
+    from qtttgym_amd import VecEnv, _native
+    n = 256
+    env = VecEnv(n)
+    L = _native.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    r = torch.empty(n, dtype=torch.float32, device="cuda")
+    tm = torch.empty(n, dtype=torch.bool, device="cuda")
+    st = env.state.data_ptr()
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, n, 0, s) == 0      # no steps
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, 0, 5, s) == 0      # no boards
+    assert L.qttt_step_random_many(None, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, n, 5, s) == -1
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), None, 0, n, 5, s) == -1              # reward without terminated
+    assert L.qttt_step_random_many(st, 1, 0, -1, 0, None, r.data_ptr(), tm.data_ptr(), 0, n, 5, s) == -2
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), -1, n, 5, s) == -2
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr() + 2, tm.data_ptr(), 0, n, 5, s) == -3
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, None, None, 0, n, 5, s) == 0                      # state only
+    with pytest.raises(ValueError):
+        env.step_random_many(3, reward=torch.empty((3, n), dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        env.step_random_many(3, actions_out=torch.empty((3, n, 2), dtype=torch.uint8, device="cuda"))
+
+
+def test_two_host_threads_with_different_launch_shapes_vs_oracle():
+    """the library is re-entrant.  Two host threads step two environments at once, each
+    with its own forced launch shape carried in the calls' flags (QTTT_FLAG_SHAPE), each on its own
+    stream; both bit-exact against the oracle."""
+    from qtttgym_amd import VecEnv, _native
+    n, T = 200001, 16
+    shapes = [(1, 256), (2, 1024)]
+    seeds = [31, 32]
+    envs = [VecEnv(n, seed=seeds[k], auto_reset=True, launch_shape=shapes[k]) for k in range(2)]
+    for k in range(2):
+        assert _native.step_launch_shape(n, envs[k]._flags()) == shapes[k]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    got = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            with torch.cuda.stream(streams[k]):
+                env = envs[k]
+                acts, rew, term = [], [], []
+                for t in range(T):
+                    a = env.sample_actions()
+                    r, tm = env.step_raw(a)
+                    acts.append(a.clone()); rew.append(r.clone()); term.append(tm.clone())
+                streams[k].synchronize()
+                got[k] = (torch.stack(acts), torch.stack(rew), torch.stack(term))
+        except Exception as e:                               # noqa: BLE001
+            errs.append(e)
+
+    torch.cuda.synchronize()                              # the environments' resets ran on the default stream
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for k in range(2):
+        ob, acts, rew, term = _oracle_random_steps(n, T, seeds[k], 0, True)
+        assert np.array_equal(_np(got[k][0]), acts), k
+        assert np.array_equal(_np(got[k][1]).view(np.uint32), rew), k
+        assert np.array_equal(_np(got[k][2]).astype(np.uint8), term), k
+        _assert_same_as_oracle(envs[k], ob, k)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000, 65536 + 7])
+def test_export_tiles_every_subset_and_misaligned_views(n):
+    """qttt_export writes through LDS tiles; any subset of its outputs may be asked for, and outputs that are
+    views offset by one board (every alignment phase of the tile copy) give the same rows."""
+    from qtttgym_amd import VecEnv
+    seed = 17 + n
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    for t in range(8):
+        a = ob.sample_actions(seed, t, 0, False)
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t, 0, False)
+    want = {"moves": ob.moves, "n_moves": ob.n_moves, "board": ob.board, "qmask": ob.qmask.view(np.int16), "n_q": ob.n_q}
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    spec = dict((k, (dt, shp)) for k, dt, shp in VecEnv._EXPORT_SPEC)
+    order = ["moves", "n_moves", "board", "qmask", "n_q"]
+    for mask in range(1, 32):
+        bufs = {k: torch.full((n + 1,) + spec[k][1], 77, dtype=spec[k][0], device="cuda") for k in order}
+        sel = [k for j, k in enumerate(order) if mask >> j & 1]
+        # odd masks write whole tensors, even ones views that start one board in
+        first = 0 if mask & 1 else 1
+        ptrs = [bufs[k][first:].data_ptr() if k in sel else None for k in order]
+        assert L.qttt_export(env.state.data_ptr(), *ptrs, n, s) == 0
+        for k in order:
+            got = _np(bufs[k])
+            if k in sel:
+                assert np.array_equal(got[first:first + n], want[k]), (mask, k)
+                assert (got[:first] == 77).all() and (got[first + n:] == 77).all(), (mask, k)
+            else:
+                assert (got == 77).all(), (mask, k)
+    assert np.array_equal(_np(env.turn()), ob.n_moves)
+    buf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert env.turn(out=buf) is buf and np.array_equal(_np(buf), ob.n_moves)
+    ex = env.export_boards()
+    for v in ex.values():
+        v.zero_()
+    assert env.export_boards(out=ex) is ex
+    for k in order:
+        assert np.array_equal(_np(ex[k]), want[k]), k
+    with pytest.raises(ValueError):
+        env.export_boards(out={**ex, "board": ex["board"][:, :8]})
+
+
+def test_export_at_the_end_of_the_game_nine_moves_and_autofill():
+    """Boards played to the end: nine real moves (round 8's x kept in the `last x` field), implicit
+    autofill moves, finished boards — every depth in one batch."""
+    from qtttgym_amd import VecEnv
+    n, seed = 20000, 8
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    for t in range(11):
+        a = ob.sample_actions(seed, t, 0, False)
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t, 0, False)
+        _assert_same_as_oracle(env, ob, t)
+    nm = ob.n_moves
+    assert (nm == 9).sum() > n // 2
+    auto = (ob.moves[np.arange(n), np.minimum(nm, 9) - 1, 0] == ob.moves[np.arange(n), np.minimum(nm, 9) - 1, 1])
+    assert auto.sum() > 100 and (~auto).sum() > 100          # both kinds of ninth move are present
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 4097, 100001])
+def test_node_info_pairs_and_expand_pairs_at_ragged_sizes(n):
+    """Two boards per lane in node_info (the last board of an odd batch alone), outputs as offset views
+    (scalar-store path), and the paired children of expand, against the oracle."""
+    from qtttgym_amd import VecEnv
+    seed = 23
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    rng = np.random.default_rng(n)
+    depth = rng.integers(0, 10, size=n)
+    for t in range(9):                                    # boards frozen at random depths 0..9
+        a = ob.sample_actions(seed, t, 0, False)
+        a[depth <= t] = 0                                  # (0,0): a noop
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t, 0, False)
+    w, tm, lg, ky = oracle.node_info(ob) if n <= 5000 else (None,) * 4
+    info = env.node_info()
+    if w is not None:
+        assert np.array_equal(_np(info["winner"]), w) and np.array_equal(_np(info["terminal"]).astype(np.uint8), tm)
+        assert np.array_equal(_np(info["legal"]).view(np.uint64), lg) and np.array_equal(_np(info["key"]), ky)
+    # offset views: one element in (misaligned for the vector stores) -> same values
+    big = {"winner": torch.zeros(n + 1, dtype=torch.int8, device="cuda"), "terminal": torch.zeros(n + 1, dtype=torch.bool, device="cuda"),
+           "legal": torch.zeros(n + 1, dtype=torch.int64, device="cuda"), "key": torch.zeros(n + 1, dtype=torch.int64, device="cuda")}
+    view = {k: v[1:] for k, v in big.items()}
+    env.node_info(out=view)
+    for k in big:
+        assert torch.equal(view[k], info[k]), k
+        assert int(big[k][0]) == 0, k
+    if n <= 5000:
+        act = rng.integers(0, 40, size=n).astype(np.uint8)      # 36..39: not an action
+        nch, kids, ow, ot, ol, ok = oracle.expand(ob, act)
+        out = env.expand(torch.from_numpy(act).cuda())
+        assert np.array_equal(_np(out["n_children"]), nch)
+        assert np.array_equal(_np(out["winner"]), ow) and np.array_equal(_np(out["terminal"]).astype(np.uint8), ot)
+        assert np.array_equal(_np(out["legal"]).view(np.uint64), ol) and np.array_equal(_np(out["key"]), ok)
+        for c in range(2):                                   # child c is meaningful where c < n_children (include/qttt.h)
+            _assert_same_as_oracle(out["child%d" % c], kids[c], (n, c), sel=nch > c)
+        # out= : the same buffers, overwritten
+        keep = {k: (v.state.data_ptr() if k.startswith("child") else v.data_ptr()) for k, v in out.items()}
+        for k, v in out.items():
+            (v.state if k.startswith("child") else v).zero_()
+        again = env.expand(torch.from_numpy(act).cuda(), out=out)
+        assert again is out
+        assert keep == {k: (v.state.data_ptr() if k.startswith("child") else v.data_ptr()) for k, v in out.items()}
+        assert np.array_equal(_np(out["key"]), ok) and np.array_equal(_np(out["n_children"]), nch)
+        for c in range(2):
+            _assert_same_as_oracle(out["child%d" % c], kids[c], (n, c, "out="), sel=nch > c)
+
+
+def test_expand_wants_aligned_rows():
+    from qtttgym_amd import VecEnv
+    n = 64
+    env = VecEnv(n)
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    c0, c1 = torch.empty_like(env.state), torch.empty_like(env.state)
+    nch = torch.empty(n, dtype=torch.uint8, device="cuda")
+    w = torch.empty(2 * n + 8, dtype=torch.int8, device="cuda")
+    tm = torch.empty(2 * n + 8, dtype=torch.uint8, device="cuda")
+    lg = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
+    ky = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
+    ok = lambda wp, tp, lp, kp: L.qttt_expand(env.state.data_ptr(), a.data_ptr(), c0.data_ptr(), c1.data_ptr(), nch.data_ptr(),
+                                              wp, tp, lp, kp, n, s)
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr()) == 0
+    assert ok(w.data_ptr() + 1, tm.data_ptr(), lg.data_ptr(), ky.data_ptr()) == -3
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr() + 8, ky.data_ptr()) == -3
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr() + 8) == -3
+
+
+def test_rollout_and_encode_out_reuse():
+    from qtttgym_amd import VecEnv
+    n = 5000
+    env = VecEnv(n, seed=3)
+    for _ in range(3):
+        env.step_raw(env.sample_actions())
+    res, pl, fin = env.rollout(return_final=True)
+    ref = (res.clone(), pl.clone(), fin.state.clone())
+    res.zero_(); pl.zero_(); fin.state.zero_()
+    out = env.rollout(return_final=True, out=(res, pl, fin))
+    assert out[0] is res and out[2] is fin
+    assert torch.equal(res, ref[0]) and torch.equal(pl, ref[1]) and torch.equal(fin.state, ref[2])
+    r2 = env.rollout(out=(res, pl))
+    assert r2[0] is res and torch.equal(res, ref[0])
+    vec, mask = env.encode()
+    v0, m0 = vec.clone(), mask.clone()
+    vec.zero_(); mask.zero_()
+    v1, m1 = env.encode(out=(vec, mask))
+    assert v1 is vec and torch.equal(vec, v0) and torch.equal(mask, m0)
+    v2 = env.encode(with_mask=False, out=vec)
+    assert v2 is vec and torch.equal(vec, v0)
+    with pytest.raises(ValueError):
+        env.encode(out=(vec[:-1], mask))
+    with pytest.raises(ValueError):
+        env.rollout(out=(res[:-1], pl))
+
+
+def test_step_returns_copies_by_default_and_takes_non_contiguous_inputs(golden):
+    """VecEnv.step() hands out fresh tensors (a caller that keeps (obs, next_obs) pairs must not see
+    them alias); copy_obs=False is the zero-copy form.  Transposed / strided uint8 device tensors are accepted."""
+    from qtttgym_amd import VecEnv
+    acts, bits = golden["actions"], golden["bits"]
+    E = bits.shape[0]
+    env, raw = VecEnv(E), VecEnv(E)
+    a0 = torch.from_numpy(acts[:, 0].copy()).cuda()
+    a1 = torch.from_numpy(acts[:, 1].copy()).cuda()
+    obs0, r0, t0, _, _ = env.step(a0.t().contiguous().t(), torch.from_numpy(bits[:, 0].copy()).cuda())   # (2,N).t(): not contiguous
+    keep = {k: v.clone() for k, v in obs0.items()}
+    wide = torch.zeros((E, 2), dtype=torch.uint8, device="cuda")
+    wide[:, 0] = torch.from_numpy(bits[:, 1].copy()).cuda()
+    obs1, r1, t1, _, _ = env.step(a1, wide[:, 0])                                                          # strided bits
+    for k in obs0:
+        assert obs0[k].data_ptr() != obs1[k].data_ptr() and torch.equal(obs0[k], keep[k]), k
+    assert r0.data_ptr() != r1.data_ptr()
+    assert np.array_equal(_np(obs1["classical"]), golden["board"][:, 1])
+    assert np.array_equal(_np(obs0["classical"]), golden["board"][:, 0])
+    o_a, _, _, _, _ = raw.step(a0, torch.from_numpy(bits[:, 0].copy()).cuda(), copy_obs=False)
+    o_b, _, _, _, _ = raw.step(a1, torch.from_numpy(bits[:, 1].copy()).cuda(), copy_obs=False)
+    assert all(o_a[k].data_ptr() == o_b[k].data_ptr() for k in o_a)                                      # the env's own buffers
+    assert np.array_equal(_np(o_b["classical"]), golden["board"][:, 1])

@@ -368,12 +368,19 @@ def test_step_random_equals_policy_then_step(n, auto_reset):
 
 
 def test_wave_per_board_study_kernel_gives_the_same_results():
-    """The mapping-study kernel (one wavefront per board) is the same function."""
-    from qtttgym_amd import VecEnv, _native
+    """The mapping-study kernel (one wavefront per board; tools/libqttt_study.so, outside the
+    product library) is the same function."""
+    import ctypes
+    import os
+    from qtttgym_amd import VecEnv
+    import __graft_entry__ as g
     n, seed = 4099, 6
     ref = VecEnv(n, seed=seed, auto_reset=True)
     env = VecEnv(n, seed=seed, auto_reset=True)
-    L = _native.lib()
+    L = ctypes.CDLL(g.build_study())
+    vp = ctypes.c_void_p
+    L.qttt_step_wave_per_board.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64, ctypes.c_uint32,
+                                           vp, vp, ctypes.c_int64, vp]
     r = torch.empty(n, dtype=torch.float32, device="cuda")
     tm = torch.empty(n, dtype=torch.bool, device="cuda")
     s = torch.cuda.current_stream().cuda_stream

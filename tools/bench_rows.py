@@ -77,9 +77,11 @@ def main():
     out.append({"row": "observe", "boards": n, "us": t * 1e6, "us_kernel_only": t_raw * 1e6, "output_bytes_per_board": 30})
     t = timed(lambda: env.export_boards(), reps=10)
     ex = env.export_boards()
+    t_out = timed(lambda: env.export_boards(out=ex), reps=20)
     t_raw = timed(lambda: env._lib.qttt_export(env.state.data_ptr(), ex["moves"].data_ptr(), ex["n_moves"].data_ptr(),
                                                ex["board"].data_ptr(), ex["qmask"].data_ptr(), ex["n_q"].data_ptr(), n, s), reps=20)
-    out.append({"row": "export", "boards": n, "us": t * 1e6, "us_kernel_only": t_raw * 1e6, "output_bytes_per_board": 37})
+    out.append({"row": "export", "boards": n, "us": t * 1e6, "us_out_reuse": t_out * 1e6, "us_kernel_only": t_raw * 1e6,
+                "output_bytes_per_board": 37})
     t = timed(lambda: env.check_win(), reps=10)
     p1, p2 = env.check_win()
     t_raw = timed(lambda: env._lib.qttt_check_win(env.state.data_ptr(), p1.data_ptr(), p2.data_ptr(), n, s), reps=20)
@@ -113,6 +115,33 @@ def main():
         out.append({"row": "step_many_T64_every_output_kept", "boards": n, "fused_us_per_step": tf * 1e6 / T,
                     "unfused_us_per_step": tu * 1e6 / T, "fused_steps_per_s": n * T / tf,
                     "unfused_steps_per_s": n * T / tu})
+    # fused random-policy stepping (qttt_step_random_many): T steps per launch, in-kernel policy
+    for n in (4096, 65536, 262144, 1 << 20):
+        T = 64
+        env = VecEnv(n, seed=2, auto_reset=True)
+        r = torch.empty((T, n), dtype=torch.float32, device="cuda")
+        tm = torch.empty((T, n), dtype=torch.bool, device="cuda")
+        a = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+        t_keep = timed(lambda: env.step_random_many(T, actions_out=a, reward=r, terminated=tm), reps=10)
+        t_rt = timed(lambda: env.step_random_many(T, reward=r, terminated=tm), reps=10)
+        t_last = timed(lambda: env.step_random_many(T), reps=10)
+        t_one = timed(lambda: env.step_random(), reps=64)
+        out.append({"row": "step_random_many_T64", "boards": n, "us_per_step_all_outputs_kept": t_keep * 1e6 / T,
+                    "us_per_step_reward_terminated_kept": t_rt * 1e6 / T, "us_per_step_last_only": t_last * 1e6 / T,
+                    "us_per_step_launch_by_launch": t_one * 1e6, "steps_per_s_all_outputs_kept": n * T / t_keep,
+                    "steps_per_s_last_only": n * T / t_last})
+    # expand and node_info at a batch that fills the chip, turn() = n_moves alone
+    n = 1 << 20
+    env = midgame(n, 4)
+    act = torch.randint(0, 36, (n,), dtype=torch.uint8, device="cuda")
+    ex = env.expand(act)
+    t = timed(lambda: env.expand(act, out=ex), reps=20)
+    t_alloc = timed(lambda: env.expand(act), reps=10)
+    out.append({"row": "expand", "boards": n, "us_out_reuse": t * 1e6, "us_allocating": t_alloc * 1e6,
+                "expansions_per_s": n / t, "algorithmic_bytes_per_pair": 17 + 32 + 1 + 4 + 32})
+    tn = env.turn()
+    t = timed(lambda: env.turn(out=tn), reps=20)
+    out.append({"row": "turn", "boards": n, "us": t * 1e6, "algorithmic_bytes_per_board": 9})
     for o in out:
         print(json.dumps(o))
 

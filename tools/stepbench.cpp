@@ -123,7 +123,11 @@ int main(int argc, char **argv) {
 #define SYM(f, name) *(void **)(&L.f) = dlsym(L.h, name); if (!L.f) { fprintf(stderr, "missing %s\n", name); return 1; }
         SYM(state_bytes, "qttt_state_bytes") SYM(reset, "qttt_reset") SYM(step, "qttt_step")
         SYM(step_many, "qttt_step_many") SYM(sample, "qttt_sample_actions") SYM(set_tuning, "qttt_set_tuning")
-        *(void **)(&L.step_wpb) = dlsym(L.h, "qttt_step_wave_per_board");   // optional
+        L.step_wpb = nullptr;
+        if (libs.empty()) {                                                  // the mapping study lives in its own library
+            if (void *hs = dlopen("tools/libqttt_study.so", RTLD_NOW | RTLD_LOCAL))
+                *(void **)(&L.step_wpb) = dlsym(hs, "qttt_step_wave_per_board");
+        }
         *(void **)(&L.step_obs) = dlsym(L.h, "qttt_step_observe");          // optional (STEPBENCH_OBS=1 times it)
         libs.push_back(L);
     }
@@ -217,10 +221,10 @@ int main(int argc, char **argv) {
         *(void **)(&set_stamps) = dlsym(L.h, "qttt_debug_set_stamps");
         if (set_stamps) {
             int eff_bpl = L.bpl, eff_blk = 0;
-            int (*shape)(int64_t, int *, int *) = nullptr;
+            int (*shape)(int64_t, uint32_t, int, int *, int *) = nullptr;   // ABI v3 signature
             *(void **)(&shape) = dlsym(L.h, "qttt_step_launch_shape");
             L.set_tuning(L.bpl, L.pipe);
-            if (shape) shape(n, &eff_bpl, &eff_blk);
+            if (shape) shape(n, 0u, 0, &eff_bpl, &eff_blk);
             if (!eff_bpl) eff_bpl = 2;
             int64_t n_waves = (n / eff_bpl + 63) / 64;
             u64 *dbuf; CK(hipMalloc(&dbuf, n_waves * 32)); CK(hipMemset(dbuf, 0, n_waves * 32));
