@@ -161,7 +161,8 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx,
  *   terminal u8[n] line or len(moves) == 9                     (mcts.py:65)
  *   legal u64[n]   bit a = action a in GameState.actions       (mcts.py:20-27, ind2move order)
  *   key i64[n]     GameState.__hash__ (mcts.py:93-94) = CPython (>= 3.8) hash(tuple(board) +
- *                  tuple(moves)), bit-exact, so keys match a host-side transposition table */
+ *                  tuple(moves)), bit-exact, so keys match a host-side transposition table
+ * Every output is nullable; only what is asked for is computed (the key is ~3/4 of the work). */
 int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,
                    int64_t *key, int64_t n, void *stream);
 

@@ -14,12 +14,17 @@ namespace {
 // plane, as the step kernel) through the same LDS tiles and the same obs_board() as the fused step
 // kernel.  A workgroup owns 2 * BLOCK consecutive boards; the last board of an odd batch is
 // read with scalar loads.
-template <int BLOCK>
+// WAVE_LUT: every wave keeps its own copy of the 128-byte selector table (lanes 0..31 copy one dword each), so
+// the kernel has no workgroup barrier at all: a wave depends on nothing but its own loads.
+template <int BLOCK, bool WAVE_LUT = true>
 __global__ __launch_bounds__(BLOCK) void observe_kernel(const u64 *pP, const u64 *pQ, ObsOut obs, int64_t n) {
     constexpr u32 TILE_BOARDS = BLOCK * 2;
     __shared__ __attribute__((aligned(16))) uint8_t otile[obs_lds_bytes(TILE_BOARDS)];
-    __shared__ __attribute__((aligned(16))) u32 olut[OBS_LUT_BYTES / 4];
-    const u32 olw = threadIdx.x < OBS_LUT_BYTES / 4 ? (&g_obs_lut.sel[0][0])[threadIdx.x] : 0u;   // see step_kernel
+    __shared__ __attribute__((aligned(16))) u32 olut_all[(WAVE_LUT ? BLOCK / 64 : 1) * (OBS_LUT_BYTES / 4)];
+    const u32 lane = threadIdx.x & 63u;
+    u32 *olut = olut_all + (WAVE_LUT ? (threadIdx.x >> 6) * (OBS_LUT_BYTES / 4) : 0u);
+    const u32 lw = WAVE_LUT ? lane : threadIdx.x;
+    const u32 olw = lw < OBS_LUT_BYTES / 4 ? (&g_obs_lut.sel[0][0])[lw] : 0u;   // requested first (see step_kernel)
     const int64_t base = (int64_t)blockIdx.x * TILE_BOARDS;
     const u32 valid = (u32)min((int64_t)TILE_BOARDS, n - base);
     const ObsTiles T = obs_tiles<TILE_BOARDS>(otile, obs, base);
@@ -33,8 +38,13 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const u64 *pP, const u64
         p.v[0] = pP[base + b0];
         q.v[0] = pQ[base + b0];
     }
-    if (threadIdx.x < OBS_LUT_BYTES / 4) olut[threadIdx.x] = olw;
-    __syncthreads();
+    if (lw < OBS_LUT_BYTES / 4) olut[lw] = olw;
+    if (WAVE_LUT) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
     if (b0 < valid) obs_board((u32)p.v[0], (u32)(p.v[0] >> 32), (u32)q.v[0], T, b0, olut);
     if (b0 + 1u < valid) obs_board((u32)p.v[1], (u32)(p.v[1] >> 32), (u32)q.v[1], T, b0 + 1u, olut);
     const u32 ph = obs_all_phases(obs, base, 15u);
@@ -115,82 +125,108 @@ __device__ __forceinline__ void exp_pairs(u32 h, u32 x, u32 &lo, u32 &hi) {
     hi = ((c & gm) | (o & ~gm)) | dead;
 }
 
-template <int BLOCK>
+// the rows of board b of the tile, from its packed words
+struct ExpTiles {
+    uint8_t *mv, *bd, *qm, *nm, *nq;                                  // already phase-shifted; null = not asked for
+};
+__device__ __forceinline__ void export_board(u64 Pw, u64 Qw, const ExpTiles &T, u32 b) {
+    const u32 P1 = (u32)(Pw >> 32), Q0 = (u32)Qw;
+    const Lite s = lite_unpack(Pw);                                   // the implicit autofill materialised
+    const u32 W = (u32)(s.P >> 2);                                    // codes of squares 0..7
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+    if (T.nm) T.nm[b] = (uint8_t)s.n;
+    if (T.bd) {
+        // Board.board: 15 - code where classical, -1 elsewhere (nibbles -> bytes with two v_perm)
+        const u32 ev = W & 0x0F0F0F0Fu, od = (W >> 4) & 0x0F0F0F0Fu;
+        const u32 c03 = __builtin_amdgcn_perm(od, ev, 0x05010400u), c47 = __builtin_amdgcn_perm(od, ev, 0x07030602u);
+        const u32 t03 = __umul24(s.cl & 0xFu, 0x204081u) & 0x01010101u;
+        const u32 t47 = __umul24((s.cl >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+        const u32 m03 = (t03 << 8) - t03, m47 = (t47 << 8) - t47;
+        const u64 o07 = (u64)((c03 ^ 0x0F0F0F0Fu) | ~m03) | ((u64)((c47 ^ 0x0F0F0F0Fu) | ~m47) << 32);
+        uint8_t *r = T.bd + b * 9u;
+        __builtin_memcpy(r, &o07, 8);
+        r[8] = (uint8_t)((s.cl & 0x100u) ? (c8 ^ 0xFu) : 0xFFu);
+    }
+    if (T.mv) {
+        u64 H = 0;                                                    // nibble (code - 7) = holder square + 1
+#pragma unroll
+        for (u32 v = 0; v < 8; ++v) H |= (u64)(v + 1u) << ((((W >> (4u * v)) & 0xFu) * 4u + 36u) & 63u);
+        H |= 9ull << ((c8 * 4u + 36u) & 63u);
+        const u32 last_x = (P1 >> P1_LX_SHIFT) & 0xFu;
+        const bool nine = s.n_real == 9u;
+        const u32 Hs = (u32)(H >> 4);                                 // nibble 7 - t = holder + 1 of round t <= 7
+        const u32 X = rotr32(Q0, 2u) ^ (nine ? last_x << 28 : 0u);     // nibble 7 - t = x of round t (round 8's x undone)
+        u32 lo_e, hi_e, lo_o, hi_o;                                   // bytes 0..3 = rounds 7,5,3,1 / 6,4,2,0
+        exp_pairs(Hs & 0x0F0F0F0Fu, X & 0x0F0F0F0Fu, lo_e, hi_e);
+        exp_pairs((Hs >> 4) & 0x0F0F0F0Fu, (X >> 4) & 0x0F0F0F0Fu, lo_o, hi_o);
+        const u32 A = __builtin_amdgcn_perm(hi_o, lo_o, 0x06020703u);       // rounds 0, 2 as (lo, hi) pairs
+        const u32 B = __builtin_amdgcn_perm(hi_e, lo_e, 0x06020703u);       // rounds 1, 3
+        const u32 C = __builtin_amdgcn_perm(hi_o, lo_o, 0x04000501u);       // rounds 4, 6
+        const u32 D = __builtin_amdgcn_perm(hi_e, lo_e, 0x04000501u);       // rounds 5, 7
+        const u64 m03 = (u64)__builtin_amdgcn_perm(B, A, 0x05040100u) | ((u64)__builtin_amdgcn_perm(B, A, 0x07060302u) << 32);
+        const u64 m47 = (u64)__builtin_amdgcn_perm(D, C, 0x05040100u) | ((u64)__builtin_amdgcn_perm(D, C, 0x07060302u) << 32);
+        const u32 h8 = (u32)H & 0xFu;                                 // round 8: the last real move or the autofill (x = 0)
+        const u32 c = h8 - 1u, o = c ^ (nine ? last_x : 0u);
+        const uint16_t m8 = h8 ? (uint16_t)(min(c, o) | (max(c, o) << 8)) : (uint16_t)0xFFFFu;
+        uint8_t *r = T.mv + b * 18u;
+        __builtin_memcpy(r, &m03, 8);
+        __builtin_memcpy(r + 8, &m47, 8);
+        __builtin_memcpy(r + 16, &m8, 2);
+    }
+    if (T.qm || T.nq) {
+        const u64 comps = (Qw >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
+        const u32 c32 = (u32)comps;
+        if (T.qm) {
+            const u64 q = (u64)((c32 & 0x1FFu) | ((c32 << 7) & 0x01FF0000u)) |
+                          ((u64)(((c32 >> 18) & 0x1FFu) | ((u32)(comps >> 11) & 0x01FF0000u)) << 32);
+            __builtin_memcpy(T.qm + b * 8u, &q, 8);
+        }
+        if (T.nq) {                                                   // slots are compact: count the non-empty ones
+            const u32 nz = ((((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u) | ((comps >> 27) ? 1u : 0u);
+            T.nq[b] = (uint8_t)__builtin_popcount(nz);
+        }
+    }
+}
+
+// BPL consecutive boards per lane (16-byte plane loads with two), a workgroup owns BLOCK * BPL boards.
+template <int BLOCK, int BPL>
 __global__ __launch_bounds__(BLOCK) void export_kernel(const u64 *pP, const u64 *pQ, ExpOut out, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[exp_lds_bytes(BLOCK)];
-    const int64_t base = (int64_t)blockIdx.x * BLOCK;
-    const u32 valid = (u32)min((int64_t)BLOCK, n - base);
-    const u32 b = threadIdx.x;
+    constexpr u32 TILE = BLOCK * BPL;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[exp_lds_bytes(TILE)];
+    const int64_t base = (int64_t)blockIdx.x * TILE;
+    const u32 valid = (u32)min((int64_t)TILE, n - base);
     // global rows of this workgroup and the tiles that mirror them (same alignment phase, see obs_tiles)
     uint8_t *g_mv = out.moves + base * 18, *g_bd = reinterpret_cast<uint8_t *>(out.board) + base * 9;
     uint8_t *g_qm = reinterpret_cast<uint8_t *>(out.qmask) + base * 8, *g_nm = out.n_moves + base, *g_nq = out.n_q + base;
-    uint8_t *l_mv = tile, *l_bd = l_mv + obs_tile_bytes(BLOCK, 18), *l_qm = l_bd + obs_tile_bytes(BLOCK, 9);
-    uint8_t *l_nm = l_qm + obs_tile_bytes(BLOCK, 8), *l_nq = l_nm + obs_tile_bytes(BLOCK, 1);
+    uint8_t *l_mv = tile, *l_bd = l_mv + obs_tile_bytes(TILE, 18), *l_qm = l_bd + obs_tile_bytes(TILE, 9);
+    uint8_t *l_nm = l_qm + obs_tile_bytes(TILE, 8), *l_nq = l_nm + obs_tile_bytes(TILE, 1);
+    ExpTiles T;
+    T.mv = out.moves ? l_mv + obs_phase(g_mv) : nullptr;
+    T.bd = out.board ? l_bd + obs_phase(g_bd) : nullptr;
+    T.qm = out.qmask ? l_qm + obs_phase(g_qm) : nullptr;
+    T.nm = out.n_moves ? l_nm + obs_phase(g_nm) : nullptr;
+    T.nq = out.n_q ? l_nq + obs_phase(g_nq) : nullptr;
     const bool want_q = out.moves || out.qmask || out.n_q;            // plane Q: the x nibbles and the comps
-    if (b < valid) {
-        const u64 Pw = load_stream(&pP[base + b]);
-        const u64 Qw = want_q ? load_stream(&pQ[base + b]) : 0ull;
-        const u32 P1 = (u32)(Pw >> 32), Q0 = (u32)Qw;
-        const Lite s = lite_unpack(Pw);                               // the implicit autofill materialised
-        const u32 W = (u32)(s.P >> 2);                                // codes of squares 0..7
-        const u32 c8 = (u32)(s.P >> 34) & 0xFu;
-        if (out.n_moves) (l_nm + obs_phase(g_nm))[b] = (uint8_t)s.n;
-        if (out.board) {
-            // Board.board: 15 - code where classical, -1 elsewhere (nibbles -> bytes with two v_perm)
-            const u32 ev = W & 0x0F0F0F0Fu, od = (W >> 4) & 0x0F0F0F0Fu;
-            const u32 c03 = __builtin_amdgcn_perm(od, ev, 0x05010400u), c47 = __builtin_amdgcn_perm(od, ev, 0x07030602u);
-            const u32 t03 = __umul24(s.cl & 0xFu, 0x204081u) & 0x01010101u;
-            const u32 t47 = __umul24((s.cl >> 4) & 0xFu, 0x204081u) & 0x01010101u;
-            const u32 m03 = (t03 << 8) - t03, m47 = (t47 << 8) - t47;
-            const u64 o07 = (u64)((c03 ^ 0x0F0F0F0Fu) | ~m03) | ((u64)((c47 ^ 0x0F0F0F0Fu) | ~m47) << 32);
-            uint8_t *r = l_bd + obs_phase(g_bd) + b * 9u;
-            __builtin_memcpy(r, &o07, 8);
-            r[8] = (uint8_t)((s.cl & 0x100u) ? (c8 ^ 0xFu) : 0xFFu);
-        }
-        if (out.moves) {
-            u64 H = 0;                                                // nibble (code - 7) = holder square + 1
+    const u32 b0 = threadIdx.x * BPL;
+    typedef Vec<u64, BPL> V64;
+    V64 p, q;
 #pragma unroll
-            for (u32 v = 0; v < 8; ++v) H |= (u64)(v + 1u) << ((((W >> (4u * v)) & 0xFu) * 4u + 36u) & 63u);
-            H |= 9ull << ((c8 * 4u + 36u) & 63u);
-            const u32 last_x = (P1 >> P1_LX_SHIFT) & 0xFu;
-            const bool nine = s.n_real == 9u;
-            const u32 Hs = (u32)(H >> 4);                             // nibble 7 - t = holder + 1 of round t <= 7
-            const u32 X = rotr32(Q0, 2u) ^ (nine ? last_x << 28 : 0u); // nibble 7 - t = x of round t (round 8's x undone)
-            u32 lo_e, hi_e, lo_o, hi_o;                               // bytes 0..3 = rounds 7,5,3,1 / 6,4,2,0
-            exp_pairs(Hs & 0x0F0F0F0Fu, X & 0x0F0F0F0Fu, lo_e, hi_e);
-            exp_pairs((Hs >> 4) & 0x0F0F0F0Fu, (X >> 4) & 0x0F0F0F0Fu, lo_o, hi_o);
-            const u32 A = __builtin_amdgcn_perm(hi_o, lo_o, 0x06020703u);   // rounds 0, 2 as (lo, hi) pairs
-            const u32 B = __builtin_amdgcn_perm(hi_e, lo_e, 0x06020703u);   // rounds 1, 3
-            const u32 C = __builtin_amdgcn_perm(hi_o, lo_o, 0x04000501u);   // rounds 4, 6
-            const u32 D = __builtin_amdgcn_perm(hi_e, lo_e, 0x04000501u);   // rounds 5, 7
-            const u64 m03 = (u64)__builtin_amdgcn_perm(B, A, 0x05040100u) | ((u64)__builtin_amdgcn_perm(B, A, 0x07060302u) << 32);
-            const u64 m47 = (u64)__builtin_amdgcn_perm(D, C, 0x05040100u) | ((u64)__builtin_amdgcn_perm(D, C, 0x07060302u) << 32);
-            const u32 h8 = (u32)H & 0xFu;                             // round 8: the last real move or the autofill (x = 0)
-            const u32 c = h8 - 1u, o = c ^ (nine ? last_x : 0u);
-            const uint16_t m8 = h8 ? (uint16_t)(min(c, o) | (max(c, o) << 8)) : (uint16_t)0xFFFFu;
-            uint8_t *r = l_mv + obs_phase(g_mv) + b * 18u;
-            __builtin_memcpy(r, &m03, 8);
-            __builtin_memcpy(r + 8, &m47, 8);
-            __builtin_memcpy(r + 16, &m8, 2);
-        }
-        if (out.qmask || out.n_q) {
-            const u64 comps = (Qw >> 32) | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
-            const u32 c32 = (u32)comps;
-            if (out.qmask) {
-                const u64 q = (u64)((c32 & 0x1FFu) | ((c32 << 7) & 0x01FF0000u)) |
-                              ((u64)(((c32 >> 18) & 0x1FFu) | ((u32)(comps >> 11) & 0x01FF0000u)) << 32);
-                __builtin_memcpy(l_qm + obs_phase(g_qm) + b * 8u, &q, 8);
-            }
-            if (out.n_q) {                                            // slots are compact: count the non-empty ones
-                const u32 nz = ((((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u) | ((comps >> 27) ? 1u : 0u);
-                (l_nq + obs_phase(g_nq))[b] = (uint8_t)__builtin_popcount(nz);
-            }
-        }
+    for (int k = 0; k < BPL; ++k) p.v[k] = q.v[k] = 0ull;
+    if (b0 + BPL <= valid) {
+        p = load_stream(&reinterpret_cast<const V64 *>(pP + base)[threadIdx.x]);
+        if (want_q) q = load_stream(&reinterpret_cast<const V64 *>(pQ + base)[threadIdx.x]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < BPL; ++k)
+            if (b0 + k < valid) { p.v[k] = pP[base + b0 + k]; if (want_q) q.v[k] = pQ[base + b0 + k]; }
     }
+#pragma unroll
+    for (int k = 0; k < BPL; ++k)
+        if (b0 + k < valid) export_board(p.v[k], q.v[k], T, b0 + k);
     const uintptr_t all = (out.moves ? (uintptr_t)g_mv : 0) | (out.board ? (uintptr_t)g_bd : 0) |
                           (out.qmask ? (uintptr_t)g_qm : 0) | (out.n_moves ? (uintptr_t)g_nm : 0) | (out.n_q ? (uintptr_t)g_nq : 0);
     if ((all & 3u) == 0u) {                                           // every wave streams out the rows it wrote
-        const u32 w0 = threadIdx.x & ~63u, w1 = min(w0 + 64u, valid);
+        const u32 w0 = (threadIdx.x & ~63u) * BPL, w1 = min(w0 + 64u * BPL, valid);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (w0 < valid) {

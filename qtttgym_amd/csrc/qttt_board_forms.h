@@ -251,6 +251,15 @@ __host__ __device__ constexpr u64 pyh_step(u64 acc, u64 lane_times_p2) {
     acc = (acc << 31) | (acc >> 33);
     return acc * PYH_P1;
 }
+// the same on the device: the 64-bit rotate by 31 as two v_alignbit_b32 (the compiler's own lowering is a
+// 64-bit shift pair + or)
+__device__ __forceinline__ u64 pyh_step_dev(u64 acc, u64 lane_times_p2) {
+    acc += lane_times_p2;
+    const u32 lo = (u32)acc, hi = (u32)(acc >> 32);
+    const u32 rlo = __builtin_amdgcn_alignbit(lo, hi, 1u);           // (lo << 31) | (hi >> 1)
+    const u32 rhi = __builtin_amdgcn_alignbit(hi, lo, 1u);           // (hi << 31) | (lo >> 1)
+    return ((u64)rlo | ((u64)rhi << 32)) * PYH_P1;
+}
 __host__ __device__ constexpr u64 pyh_fin(u64 acc, u64 len) {
     acc += len ^ (PYH_P5 ^ 3527539ull);
     return acc == ~0ull ? 1546275796ull : acc;
@@ -305,14 +314,14 @@ struct PyHashWalk {
     }
     __device__ __forceinline__ void board_elem(u32 v, u32 cl, const u64 *tbl) {
         const u32 c = v < 8u ? (W >> (4u * v)) & 0xFu : c8;
-        acc = pyh_step(acc, tbl[(cl >> v & 1u) ? 16u - c : 0u]);    // board[value + 1], value = 15 - c
+        acc = pyh_step_dev(acc, tbl[(cl >> v & 1u) ? 16u - c : 0u]);   // board[value + 1], value = 15 - c
     }
     __device__ __forceinline__ void move_elem(u32 t, const u64 *tbl) {   // t < n8 (an autofill move is always round 8)
         const u32 z = W ^ kk;
         const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
         const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
         const u32 o = min(c ^ ((Qr >> sh) & 0xFu), 8u);             // (only a corrupted import could exceed 8)
-        acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + t]);
+        acc = pyh_step_dev(acc, tbl[10u + (c * 9u + o) * 9u + t]);
         kk -= 0x11111111u;
         sh = (sh - 4u) & 31u;
     }
@@ -322,7 +331,7 @@ struct PyHashWalk {
             const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
             const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
             const u32 o = min(c ^ (nine_real ? last_x : 0u), 8u);   // autofill = (idx, idx)
-            acc = pyh_step(acc, tbl[10u + (c * 9u + o) * 9u + 8u]);
+            acc = pyh_step_dev(acc, tbl[10u + (c * 9u + o) * 9u + 8u]);
         }
         return (int64_t)pyh_fin(acc, 9u + n);
     }

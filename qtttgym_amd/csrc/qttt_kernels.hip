@@ -345,9 +345,8 @@ int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     if (((uintptr_t)q_p1 & 1u) || ((uintptr_t)q_p2 & 7u)) return QTTT_ERR_ACTION;   // 2- / 8-byte LDS row stores
     Planes p = planes(const_cast<void *>(state), n);
     const ObsOut o = {classical, q_p1, q_p1_len, q_p2, q_p2_len, turn};
-    // 256-thread workgroups: best or tied at every batch size for this write-heavy kernel (us per launch,
-    // 256 / 512 / 1024 threads: 65 536 boards 3.9 / 4.3 / 5.6, 262 144: 4.9 / 4.8 / 6.2, 1 M: 9.0 / 9.3 / 9.6,
-    // 4 M: 33.6 / 34.8 / 38.6)
+    // 256-thread workgroups: best or tied at every batch size for this write-heavy kernel (tools/rowbench, us per
+    // launch, 256 / 512 / 1024 threads: 65 536 boards 3.7 / 4.1 / 5.2, 1 M: 8.7 / 8.7 / 8.6)
     const int blk_default = tuning_word().load(std::memory_order_relaxed) >> 8;
     const int blk = blk_default ? blk_default : 256;
 #define QTTT_OBSERVE(BLK) hipLaunchKernelGGL((observe_kernel<BLK>), dim3((unsigned)((n + 2 * (BLK) - 1) / (2 * (BLK)))), \
@@ -378,8 +377,15 @@ int qttt_export(const void *state, uint8_t *moves, uint8_t *n_moves, int8_t *boa
     if ((uintptr_t)qmask & 1u) return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n);
     const ExpOut o = {moves, n_moves, board, qmask, n_q};
-    hipLaunchKernelGGL((export_kernel<QTTT_COLD_BLOCK>), dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0,
-                       (hipStream_t)stream, p.P, p.Q, o, n);
+    // tools/rowbench (profiles/r03/rowbench_*.txt), us per launch, boards per lane x workgroup size:
+    //   1 M boards: 1 x 256 / 512 / 1024 = 13.7 / 14.1 / 12.7, 2 x 256 / 512 / 1024 = 9.2 / 9.4 / 9.4 (one occupancy round)
+    //   64 K boards: 1 x 256 = 3.3, 2 x 256 = 3.8 (latency-bound: more waves in flight win)
+    if (n >= 384 * 1024)
+        hipLaunchKernelGGL((export_kernel<QTTT_COLD_BLOCK, 2>), dim3(cold_grid_for((n + 1) / 2)), dim3(QTTT_COLD_BLOCK), 0,
+                           (hipStream_t)stream, p.P, p.Q, o, n);
+    else
+        hipLaunchKernelGGL((export_kernel<QTTT_COLD_BLOCK, 1>), dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0,
+                           (hipStream_t)stream, p.P, p.Q, o, n);
     return launch_status();
 }
 
@@ -428,7 +434,8 @@ int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_
                    int64_t *key, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
-    if (!state || !winner || !terminal || !legal || !key) return QTTT_ERR_NULL;
+    if (!state) return QTTT_ERR_NULL;
+    if (!winner && !terminal && !legal && !key) return 0;                   // nothing asked for
     Planes p = planes(const_cast<void *>(state), n);
     hipLaunchKernelGGL(node_info_kernel, dim3(grid_for((n + 1) / 2)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
                        p.P, p.Q, winner, terminal, (u64 *)legal, key, n);

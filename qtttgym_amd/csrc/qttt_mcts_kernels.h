@@ -35,41 +35,52 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
     p.v[0] = p.v[1] = q.v[0] = q.v[1] = 0ull;
     if (i0 + 1 < n) {                                                   // requested before the table fills
         p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]);
-        q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);
+        if (key) q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);   // plane Q: only the hash reads it (the x nibbles)
     } else if (i0 < n) {
         p.v[0] = pP[i0];
-        q.v[0] = pQ[i0];
+        if (key) q.v[0] = pQ[i0];
     }
-    fill_pyhash_lut<QTTT_BLOCK>(htbl);
-    fill_legal_lut<QTTT_BLOCK>(ltbl);
+    if (key) fill_pyhash_lut<QTTT_BLOCK>(htbl);
+    if (legal) fill_legal_lut<QTTT_BLOCK>(ltbl);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i0 >= n) return;
     const Lite sa = lite_unpack(p.v[0]), sb = lite_unpack(p.v[1]);
-    int wa, ta, wb, tb;
-    lite_update_winner(sa, lut, wa, ta);
-    lite_update_winner(sb, lut, wb, tb);
-    int64_t ka, kb;
-    fast_py_hash_pair(sa, (u32)(p.v[0] >> 32), (u32)q.v[0], sb, (u32)(p.v[1] >> 32), (u32)q.v[1], htbl, ka, kb);
-    const u64 la = ltbl[sa.cl], lb = ltbl[sb.cl];
     const bool two = i0 + 1 < n;
-    if (two && ((reinterpret_cast<uintptr_t>(winner) | reinterpret_cast<uintptr_t>(terminal)) & 1u) == 0u) {
-        reinterpret_cast<uint16_t *>(winner)[j] = (uint16_t)((u32)(wa & 0xFF) | ((u32)(wb & 0xFF) << 8));
-        reinterpret_cast<uint16_t *>(terminal)[j] = (uint16_t)((u32)ta | ((u32)tb << 8));
-    } else {
-        winner[i0] = (int8_t)wa;
-        terminal[i0] = (uint8_t)ta;
-        if (two) { winner[i0 + 1] = (int8_t)wb; terminal[i0 + 1] = (uint8_t)tb; }
+    if (winner || terminal) {
+        int wa, ta, wb, tb;
+        lite_update_winner(sa, lut, wa, ta);
+        lite_update_winner(sb, lut, wb, tb);
+        if (two && ((reinterpret_cast<uintptr_t>(winner) | reinterpret_cast<uintptr_t>(terminal)) & 1u) == 0u) {
+            if (winner) reinterpret_cast<uint16_t *>(winner)[j] = (uint16_t)((u32)(wa & 0xFF) | ((u32)(wb & 0xFF) << 8));
+            if (terminal) reinterpret_cast<uint16_t *>(terminal)[j] = (uint16_t)((u32)ta | ((u32)tb << 8));
+        } else {
+            if (winner) { winner[i0] = (int8_t)wa; if (two) winner[i0 + 1] = (int8_t)wb; }
+            if (terminal) { terminal[i0] = (uint8_t)ta; if (two) terminal[i0 + 1] = (uint8_t)tb; }
+        }
     }
-    if (two && ((reinterpret_cast<uintptr_t>(legal) | reinterpret_cast<uintptr_t>(key)) & 15u) == 0u) {
-        V64 l2, k2;
-        l2.v[0] = la; l2.v[1] = lb;
-        k2.v[0] = (u64)ka; k2.v[1] = (u64)kb;
-        store_stream(&reinterpret_cast<V64 *>(legal)[j], l2);
-        store_stream(&reinterpret_cast<V64 *>(key)[j], k2);
-    } else {
-        legal[i0] = la;
-        key[i0] = ka;
-        if (two) { legal[i0 + 1] = lb; key[i0 + 1] = kb; }
+    typedef Vec<u64, 2> V64x;
+    if (legal) {
+        const u64 la = ltbl[sa.cl], lb = ltbl[sb.cl];
+        if (two && (reinterpret_cast<uintptr_t>(legal) & 15u) == 0u) {
+            V64x l2;
+            l2.v[0] = la; l2.v[1] = lb;
+            store_stream(&reinterpret_cast<V64x *>(legal)[j], l2);
+        } else {
+            legal[i0] = la;
+            if (two) legal[i0 + 1] = lb;
+        }
+    }
+    if (key) {                                             // the expensive part: skipped when the caller keeps no table
+        int64_t ka, kb;
+        fast_py_hash_pair(sa, (u32)(p.v[0] >> 32), (u32)q.v[0], sb, (u32)(p.v[1] >> 32), (u32)q.v[1], htbl, ka, kb);
+        if (two && (reinterpret_cast<uintptr_t>(key) & 15u) == 0u) {
+            V64x k2;
+            k2.v[0] = (u64)ka; k2.v[1] = (u64)kb;
+            store_stream(&reinterpret_cast<V64x *>(key)[j], k2);
+        } else {
+            key[i0] = ka;
+            if (two) key[i0 + 1] = kb;
+        }
     }
 }
 

@@ -229,12 +229,11 @@ __device__ __forceinline__ void obs_board(u32 P0, u32 P1, u32 Q0, const ObsTiles
     u32 a0, a1, b0, b1;
     const u32 n1 = obs_list((H >> 4) & 0x0F0F0F0Fu, (X >> 4) & 0x0F0F0F0Fu, olut, a0, a1);   // even rounds
     const u32 n2 = obs_list(H & 0x0F0F0F0Fu, X & 0x0F0F0F0Fu, olut, b0, b1);                 // odd rounds
-    uint16_t *r1 = reinterpret_cast<uint16_t *>(T.p1 + b * 10u);
-    r1[0] = (uint16_t)a0;
-    r1[1] = (uint16_t)(a0 >> 16);
-    r1[2] = (uint16_t)a1;
-    r1[3] = (uint16_t)(a1 >> 16);
-    r1[4] = (uint16_t)0xFFFFu;                            // round 8 can never be un-collapsed
+    uint8_t *r1 = T.p1 + b * 10u;                         // a 10-byte row: one 8-byte and one 2-byte LDS store
+    const u64 a01 = (u64)a0 | ((u64)a1 << 32);
+    const uint16_t pad = (uint16_t)0xFFFFu;               // round 8 can never be un-collapsed
+    __builtin_memcpy(r1, &a01, 8);
+    __builtin_memcpy(r1 + 8, &pad, 2);
     *reinterpret_cast<u64 *>(T.p2 + b * 8u) = (u64)b0 | ((u64)b1 << 32);
     T.l1[b] = (uint8_t)n1;
     T.l2[b] = (uint8_t)n2;

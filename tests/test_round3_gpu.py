@@ -304,11 +304,12 @@ def test_rollout_and_encode_out_reuse():
     for _ in range(3):
         env.step_raw(env.sample_actions())
     res, pl, fin = env.rollout(return_final=True)
-    ref = (res.clone(), pl.clone(), fin.state.clone())
+    planes = lambda st: st.view(torch.int64).view(2, -1)[:, :n]      # P | Q planes without the padding to 64 boards
+    ref = (res.clone(), pl.clone(), planes(fin.state).clone())
     res.zero_(); pl.zero_(); fin.state.zero_()
     out = env.rollout(return_final=True, out=(res, pl, fin))
     assert out[0] is res and out[2] is fin
-    assert torch.equal(res, ref[0]) and torch.equal(pl, ref[1]) and torch.equal(fin.state, ref[2])
+    assert torch.equal(res, ref[0]) and torch.equal(pl, ref[1]) and torch.equal(planes(fin.state), ref[2])
     r2 = env.rollout(out=(res, pl))
     assert r2[0] is res and torch.equal(res, ref[0])
     vec, mask = env.encode()
