@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — vectorised env.step()/s at batch = 1 048 576 boards per MI355X (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B] [--mode replay|gym|policy|random]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--boards B | --total-boards N]
+                    [--mode replay|gym|policy|random|random-fused] [--no-legs]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one launch of the fused qttt_step kernel over the whole batch of B boards of this
@@ -22,7 +23,14 @@ collective; one RCCL all_reduce of episode counters after the timed regions.  `-
 WORLD_SIZE in the environment starts its own N ranks (one process per GPU) before anything touches
 the GPU; under torchrun the ranks are taken from the environment.  `ranks_seen` is an all_reduce
 of ones over the process group; the line is refused unless n_gpus == ranks_seen.
-`--boards 262144 --gpus 8` is BASELINE config 4 (2 097 152 boards over 8 GPUs).
+`--total-boards 2097152 --gpus 8` is BASELINE config 4 as stated (2 097 152 boards sharded over 8 GPUs with
+dist.shard_range: STRONG scaling, the JSON says so); `--boards B` is per GPU (weak scaling, the default).
+
+Legs.  At N = 1 the same JSON object carries `legs`: the other BASELINE configurations and modes measured
+in the same process on the same clock (HIP events, median region) — env.step replay at 4 096 / 262 144 /
+16 777 216 boards (the last cannot live in the 256 MB Infinity Cache), `gym` and `random` at 1 M, the fused
+random-policy multi-step kernel (qttt_step_random_many) at 4 096 / 262 144 / 1 M, and BASELINE config 5's
+unit (expand + node_info + rollout on 65 536 boards).  Each with us per launch, algorithmic bytes, frac.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -51,17 +59,23 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--boards", type=int, default=1 << 20,
-                    help="boards per GPU (262144 with --gpus 8 = BASELINE config 4)")
+    ap.add_argument("--boards", type=int, default=1 << 20, help="boards per GPU (weak scaling)")
+    ap.add_argument("--total-boards", type=int, default=0,
+                    help="boards over ALL GPUs, sharded with dist.shard_range (strong scaling; "
+                         "2097152 with --gpus 8 = BASELINE config 4); overrides --boards")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (other configs / modes) at N = 1")
+    ap.add_argument("--fused-steps", type=int, default=64, help="steps per launch of --mode random-fused")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--regions", type=int, default=0, help="repeat count of the K-step timed region (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline")
-    ap.add_argument("--mode", choices=["replay", "gym", "policy", "random"], default="replay",
+    ap.add_argument("--mode", choices=["replay", "gym", "policy", "random", "random-fused"], default="replay",
                     help="replay: timed region is env.step only (default, the metric); "
                          "gym: env.step returning the observation too (step + obs fused in one kernel); "
                          "policy: policy kernel + env.step per step; "
-                         "random: policy and env.step fused in one kernel per step")
+                         "random: policy and env.step fused in one kernel per step; "
+                         "random-fused: the same, --fused-steps steps per launch with the boards in registers "
+                         "(qttt_step_random_many, every step's action / reward / terminated kept)")
     return ap.parse_args(argv)
 
 
@@ -126,22 +140,36 @@ def pmc_traffic_per_launch(boards, state_bytes, suffix=""):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(actions_host, seed, budget_s):
     """Times the CPU oracle (oracle/qttt_oracle.c, a scalar C port of the reference algorithm)
     on this box's host cores, on a bounded sample of the same workload: the recorded steps of a
-    slice of the boards, one slice per thread, replayed (reset + replay) until ~budget_s seconds
-    of wall time have been spent on every thread."""
+    slice of the boards, one slice per thread, replayed (reset + replay) until the budget of wall
+    time has been spent on every thread.  Two passes: ONE thread (a quarter of the budget, `threads1`)
+    and all the threads of this GPU's CPU share (`value`, `cores`); SURVEY.md §8(d) asks for both,
+    with the box's nproc and CPU model beside them."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     import oracle
     T, n = actions_host.shape[0], actions_host.shape[1]
-    cores = max(1, min(os.cpu_count() or 1, 16))   # the GPU box's CPU share for one GPU
+    nproc = os.cpu_count() or 1
+    cores = max(1, min(nproc, 16))                 # the GPU box's CPU share for one GPU
     per = n // cores
     slices = [np.ascontiguousarray(actions_host[:, k * per:(k + 1) * per]) for k in range(cores)]
 
-    def work(k):
+    def work(k, budget):
         done, passes = 0, 0
-        t_end = time.perf_counter() + budget_s
+        t_end = time.perf_counter() + budget
         while True:
             ob = oracle.OracleBoards(per)            # reset
             for t in range(T):
@@ -151,16 +179,21 @@ def cpu_baseline(actions_host, seed, budget_s):
                     return done, passes
             passes += 1
     t0 = time.perf_counter()
+    one = work(0, budget_s * 0.25)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        res = list(ex.map(work, range(cores)))
+        res = list(ex.map(lambda k: work(k, budget_s), range(cores)))
     dt = time.perf_counter() - t0
     total = sum(r[0] for r in res)
     py = python_interpreter_line(actions_host, seed)
     return {"value": total / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "threads1": one[0] / dt1, "nproc": nproc, "cpu_model": cpu_model(),
             "python_interpreter_steps_per_s": py,
             "sample": "%d boards x the first %d recorded steps of the same workload (uniform-legal policy, "
-                      "auto-reset), replayed from reset %.1f times, %d threads x %d boards, %.1f s of wall time"
-                      % (per * cores, T, total / float(per * cores * T), cores, per, dt)}
+                      "auto-reset), replayed from reset %.1f times, %d threads x %d boards, %.1f s of wall time; "
+                      "threads1: one of those slices on one thread, %.1f s"
+                      % (per * cores, T, total / float(per * cores * T), cores, per, dt, dt1)}
 
 
 def python_interpreter_line(actions_host, seed, budget_s=2.0):
@@ -191,11 +224,212 @@ def median(xs):
     return s[m] if len(s) & 1 else 0.5 * (s[m - 1] + s[m])
 
 
+# ---------------------------------------------------------------------------- one workload, one clock
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz, 4 cycles each
+
+
+def kernel_label(mode, bpl, blk):
+    if mode == "random-fused":
+        return "step_random_fused_kernel<256, true>"
+    if mode == "random":
+        return "step_kernel<%d, %d, false, true, true, false>" % (blk, bpl)
+    step = "step_kernel<%d, %d, false, true, false, %s>" % (blk, bpl, "true" if mode == "gym" else "false")
+    return ("sample_actions_kernel + " + step) if mode == "policy" else step
+
+
+WHAT = {"replay": "recorded actions replayed (env.step only in the timed region)",
+        "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel)",
+        "policy": "policy kernel + env.step per step",
+        "random": "policy + env.step fused in one kernel per step",
+        "random-fused": "policy + env.step, %d steps per launch with the boards in registers, every step's "
+                        "action / reward / terminated kept"}
+
+
+class Workload:
+    """B boards on one device, uniform-legal policy, auto-reset: records the action stream (untimed), then
+    times regions of W warm-up + EXACTLY K steps with HIP events on the launch stream."""
+
+    def __init__(self, torch, dev, B, K, W, seed, board_offset, mode, fused_T):
+        from qtttgym_amd import VecEnv, _native
+        self.torch, self.dev, self.B, self.K, self.W, self.mode, self.fused_T = torch, dev, B, K, W, mode, fused_T
+        T = K + W
+        self.env = env = VecEnv(B, device=dev, seed=seed, auto_reset=True, board_offset=board_offset)
+        self.state_bytes = int(_native.lib().qttt_state_bytes(64)) // 64
+        gym = mode == "gym"
+        # algorithmic bytes per board-step: state r+w, action, reward f32, terminated (+ the 30-byte
+        # observation of env.py:68-85 in gym mode: classical 9, q_p1 10+1, q_p2 8+1, turn 1).  The fused
+        # multi-step form keeps the boards in registers: 7 B of outputs per step + the state once per launch
+        self.algo_bytes = 2 * self.state_bytes + 2 + 4 + 1 + (30 if gym else 0)
+        if mode == "random-fused":
+            self.algo_bytes = 7.0 + 2.0 * self.state_bytes / fused_T
+        self.shape = _native.step_launch_shape(B, 0, gym)
+        # ---- untimed: record the action stream of the uniform-legal policy
+        self.actions = actions = torch.empty((T, B, 2), dtype=torch.uint8, device=dev)
+        self.term_count = torch.zeros((), dtype=torch.int64, device=dev)
+        self.win_count = torch.zeros((), dtype=torch.int64, device=dev)
+        for t in range(T):
+            env.sample_actions(out=actions[t])
+            r, tm = env.step_raw(actions[t])
+            if t >= W:
+                self.term_count += tm.sum()
+                self.win_count += (r != 0).sum()
+        torch.cuda.synchronize(dev)
+        self.final_state = env.state.clone()
+        if mode == "random-fused":
+            Tf = min(fused_T, K)
+            self.f_act = torch.empty((Tf, B, 2), dtype=torch.uint8, device=dev)
+            self.f_rew = torch.empty((Tf, B), dtype=torch.float32, device=dev)
+            self.f_term = torch.empty((Tf, B), dtype=torch.bool, device=dev)
+        self.ev0 = torch.cuda.Event(enable_timing=True)
+        self.ev1 = torch.cuda.Event(enable_timing=True)
+
+    def preroll(self):
+        """back to the recorded state after W steps (the contract's W untimed warm-up steps)"""
+        self.env.reset_raw()
+        if self.W:
+            self.env.step_many(self.actions[:self.W])
+
+    def timed_steps(self):
+        env, K, W, mode = self.env, self.K, self.W, self.mode
+        if mode == "replay":
+            env.step_many(self.actions[W:])
+        elif mode == "gym":
+            for t in range(K):
+                env.step_observe_raw(self.actions[W + t])
+        elif mode == "policy":
+            for t in range(K):
+                env.step_raw(env.sample_actions())
+        elif mode == "random":
+            for t in range(K):
+                env.step_random()
+        else:                                                     # random-fused: exactly K steps, <= fused_T per launch
+            done = 0
+            while done < K:
+                t = min(self.fused_T, K - done)
+                env.step_random_many(t, actions_out=self.f_act[:t], reward=self.f_rew[:t], terminated=self.f_term[:t])
+                done += t
+
+    def region(self, barrier):
+        """One bracket = barrier + synchronize, W untimed steps, EXACTLY K timed steps, synchronize +
+        barrier.  The W warm-up launches are enqueued right in front of the timed ones without a
+        host synchronise in between: the stream is then still busy when the K timed launches are
+        queued, so the HIP events around them read the K kernels back to back — what rocprofv3's
+        kernel trace shows for the same dispatches — and not the host's first-launch latency onto
+        an idle stream (a fixed ~5-15 us per region, 3-10 % at K = 20)."""
+        torch = self.torch
+        torch.cuda.synchronize(self.dev)
+        barrier()
+        t0 = time.perf_counter()
+        self.preroll()
+        self.ev0.record()
+        self.timed_steps()
+        self.ev1.record()
+        torch.cuda.synchronize(self.dev)
+        t1 = time.perf_counter()
+        barrier()
+        return self.ev0.elapsed_time(self.ev1) * 1e-3, (t1 - t0) * self.K / float(self.K + self.W)
+
+    def measure(self, barrier, all_max, regions=0, target_s=TARGET_TIMED_S, min_regions=5, max_regions=MAX_REGIONS):
+        pilot_ev, _ = self.region(barrier)                        # also the first-touch / clock ramp pass
+        pilot_ev = all_max(pilot_ev)
+        R = regions if regions > 0 else int(min(max_regions, max(min_regions, math.ceil(target_s / max(pilot_ev, 1e-6)))))
+        ev_s, wall_s = [], []
+        for _ in range(R):
+            e, w = self.region(barrier)
+            ev_s.append(e)
+            wall_s.append(w)
+        self.replay_ok = bool(self.torch.equal(self.env.state, self.final_state))
+        # MAX over ranks of each rank's median region
+        return all_max(median(ev_s)), all_max(min(ev_s)), all_max(median(wall_s)), R
+
+
+def run_legs(torch, dev, args):
+    """The other BASELINE configurations and modes, same process, same clock (N = 1 only)."""
+    legs = []
+    no_barrier = lambda: None
+    ident = lambda x: float(x)
+
+    def step_leg(name, B, mode, K, W, fused_T=64, **kw):
+        w = Workload(torch, dev, B, K, W, args.seed, 0, mode, fused_T)
+        ev, ev_min, _, R = w.measure(no_barrier, ident, target_s=0.02, max_regions=100, **kw)
+        us = ev / K * 1e6
+        leg = {"name": name, "boards": B, "mode": mode, "kernel": kernel_label(mode, *w.shape), "steps": K, "warmup": W,
+               "regions": R, "us_per_step": us, "best_region_us_per_step": ev_min / K * 1e6, "steps_per_s": B * K / ev,
+               "algorithmic_bytes_per_board_step": w.algo_bytes, "achieved_GBps": w.algo_bytes * B / (ev / K) / 1e9,
+               "frac": w.algo_bytes * B / (ev / K) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+               "replay_matches_recording": w.replay_ok}
+        if mode == "random-fused":
+            # VALU-bound (the boards never leave the registers): SQ_INSTS_VALU per board-step from
+            # profiles/r03/pmc_sq_fused_summary.csv against the chip's wave-instruction issue rate
+            leg.update(bound="valu", steps_per_launch=min(fused_T, K), us_per_launch=us * min(fused_T, K),
+                       valu_insts_per_board_step=FUSED_VALU_PER_STEP,
+                       valu_frac=None if FUSED_VALU_PER_STEP is None else
+                       FUSED_VALU_PER_STEP * (B / 64.0) / (ev / K * 1e9) / VALU_PEAK_GINST)
+        else:
+            leg["us_per_launch"] = us
+        legs.append(leg)
+        del w
+        torch.cuda.empty_cache()
+
+    step_leg("config2_4096_boards", 4096, "replay", 200, 20)
+    step_leg("config3_262144_boards", 262144, "replay", 200, 20)
+    step_leg("beyond_infinity_cache_16777216_boards", 16777216, "replay", 10, 2, min_regions=5)
+    step_leg("gym_1048576_boards", 1 << 20, "gym", 100, 10)
+    step_leg("random_1048576_boards", 1 << 20, "random", 100, 10)
+    step_leg("random_fused_1048576_boards", 1 << 20, "random-fused", 128, 10)
+    step_leg("random_fused_262144_boards", 262144, "random-fused", 128, 10)
+    step_leg("random_fused_4096_boards", 4096, "random-fused", 128, 10)
+    legs.append(config5_leg(torch, dev, args))
+    return legs
+
+
+FUSED_VALU_PER_STEP = None   # set from profiles/ once measured (tools/pmc_sq_summary.py)
+
+
+def config5_leg(torch, dev, args, n=65536, K=50):
+    """BASELINE config 5's unit: one batched MCTS expansion of 65 536 (state, action) pairs + the node
+    bookkeeping of the parents + one fused random playout per board, through VecEnv with reused buffers
+    (mcts.py:233-267, 20-27 / 52-65 / 93-94, 185-198), timed as one unit."""
+    from qtttgym_amd import VecEnv
+    env = VecEnv(n, device=dev, seed=args.seed)
+    for _ in range(4):
+        env.step_raw(env.sample_actions())
+    act = torch.randint(0, 36, (n,), dtype=torch.uint8, device=dev)
+    ex, ni, ro = env.expand(act), env.node_info(), env.rollout()
+
+    def unit():
+        env.expand(act, out=ex)
+        env.node_info(out=ni)
+        env.rollout(out=ro)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    us = []
+    for _ in range(8):
+        for _ in range(5):
+            unit()
+        e0.record()
+        for _ in range(K):
+            unit()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us.append(e0.elapsed_time(e1) * 1e3 / K)
+    sb = env.state.numel() // ((n + 63) // 64 * 64)
+    # expand: state + action in, two children + n_children + per-child winner/terminal/legal/key out;
+    # node_info: state in, 18 B out; rollout: state in, result + plies out
+    algo = (sb + 1 + 2 * sb + 1 + 2 * (1 + 1 + 8 + 8)) + (sb + 18) + (sb + 2)
+    u = median(us)
+    return {"name": "config5_expand_node_info_rollout_65536_boards", "boards": n, "mode": "mcts-unit",
+            "kernel": "expand_kernel + node_info_kernel + rollout_kernel", "steps": K, "regions": len(us),
+            "us_per_unit": u, "best_region_us_per_unit": min(us), "expansions_per_s": n / (u * 1e-6),
+            "algorithmic_bytes_per_board_unit": algo, "achieved_GBps": algo * n / (u * 1e-6) / 1e9,
+            "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "launch + valu (3 kernels, 65 536 boards each)"}
+
+
 # ---------------------------------------------------------------------------- one rank
 def run(args):
     import torch
     import torch.distributed as dist
-    from qtttgym_amd import VecEnv, _native
+    from qtttgym_amd import _native
+    from qtttgym_amd.dist import shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -247,81 +481,18 @@ def run(args):
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(ones)
 
-    B, K, W = args.boards, args.steps, args.warmup
-    T = K + W
-    env = VecEnv(B, device=dev, seed=args.seed, auto_reset=True, board_offset=rank * B)
-    state_bytes = int(_native.lib().qttt_state_bytes(64)) // 64
-    gym = args.mode == "gym"
-    # algorithmic bytes per board-step: state r+w, action, reward f32, terminated (+ the 30-byte
-    # observation of env.py:68-85 in gym mode: classical 9, q_p1 10+1, q_p2 8+1, turn 1)
-    algo_bytes = 2 * state_bytes + 2 + 4 + 1 + (30 if gym else 0)
-
-    # ---- untimed: record the action stream of the uniform-legal policy ------------------
-    actions = torch.empty((T, B, 2), dtype=torch.uint8, device=dev)
-    term_count = torch.zeros((), dtype=torch.int64, device=dev)
-    win_count = torch.zeros((), dtype=torch.int64, device=dev)
-    for t in range(T):
-        env.sample_actions(out=actions[t])
-        r, tm = env.step_raw(actions[t])
-        if t >= W:
-            term_count += tm.sum()
-            win_count += (r != 0).sum()
-    torch.cuda.synchronize(dev)
-    final_state = env.state.clone()
-
-    def preroll():
-        """back to the recorded state after W steps (the contract's W untimed warm-up steps)"""
-        env.reset_raw()
-        if W:
-            env.step_many(actions[:W])
-
-    def timed_steps():
-        if args.mode == "replay":
-            env.step_many(actions[W:])
-        elif gym:
-            for t in range(K):
-                env.step_observe_raw(actions[W + t])
-        elif args.mode == "policy":
-            for t in range(K):
-                env.step_raw(env.sample_actions())
-        else:
-            for t in range(K):
-                env.step_random()
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-
-    def region():
-        """One bracket = barrier + synchronize, W untimed steps, EXACTLY K timed steps, synchronize +
-        barrier.  The W warm-up launches are enqueued right in front of the timed ones without a
-        host synchronise in between: the stream is then still busy when the K timed launches are
-        queued, so the HIP events around them read the K kernels back to back — what rocprofv3's
-        kernel trace shows for the same dispatches — and not the host's first-launch latency onto
-        an idle stream (a fixed ~5-15 us per region, 3-10 % at K = 20)."""
-        torch.cuda.synchronize(dev)
-        barrier()
-        t0 = time.perf_counter()
-        preroll()
-        ev0.record()
-        timed_steps()
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        barrier()
-        return ev0.elapsed_time(ev1) * 1e-3, (t1 - t0) * K / float(K + W)
-
-    pilot_ev, _ = region()                                   # also the first-touch / clock ramp pass
-    pilot_ev = all_max(pilot_ev)
-    R = args.regions if args.regions > 0 else int(min(MAX_REGIONS, max(5, math.ceil(TARGET_TIMED_S / max(pilot_ev, 1e-6)))))
-    ev_s, wall_s = [], []
-    for _ in range(R):
-        e, w = region()
-        ev_s.append(e)
-        wall_s.append(w)
-    replay_ok = bool(torch.equal(env.state, final_state))
-    # MAX over ranks of each rank's median region
-    ev_med, wall_med = all_max(median(ev_s)), all_max(median(wall_s))
-    ev_min = all_max(min(ev_s))
+    K, W = args.steps, args.warmup
+    strong = args.total_boards > 0
+    if strong:                                   # BASELINE config 4's shape: a fixed total, sharded
+        lo, hi = shard_range(args.total_boards, rank, world)
+        B, offset, total = hi - lo, lo, args.total_boards
+    else:
+        B, offset, total = args.boards, rank * args.boards, args.boards * world
+    wl = Workload(torch, dev, B, K, W, args.seed, offset, args.mode, args.fused_steps)
+    env, state_bytes, algo_bytes = wl.env, wl.state_bytes, wl.algo_bytes
+    ev_med, ev_min, wall_med, R = wl.measure(barrier, all_max, regions=args.regions)
+    replay_ok = wl.replay_ok
+    term_count, win_count = wl.term_count, wl.win_count
 
     gather = None
     if use_dist:
@@ -350,47 +521,46 @@ def run(args):
                   file=sys.stderr)
             rc = 3
         else:
-            launch_s = ev_med / K
-            value = B * K * world / ev_med
+            launch_s = ev_med / K                                          # per env step (= per launch unless fused)
+            value = total * K / ev_med
             achieved = algo_bytes * B / launch_s / 1e9
-            bpl, blk = _native.step_launch_shape(B)                        # the library's own choice for this batch
-            kernel = ("step_kernel<%d, %d, false, true, false, %s>" % (blk, bpl, "true" if gym else "false")
-                      if args.mode in ("replay", "gym") else
-                      "step_kernel<%d, %d, false, true, true, false>" % (blk, bpl) if args.mode == "random" else
-                      "sample_actions_kernel + step_kernel<%d, %d, false, true, false, false>" % (blk, bpl))
+            bpl, blk = wl.shape                                            # the library's own choice for this batch
+            gym = args.mode == "gym"
             traffic = (pmc_traffic_per_launch(B, state_bytes) if args.mode == "replay" else
                        pmc_traffic_per_launch(B, state_bytes, "+gym") if gym else None)
-            what = {"replay": "recorded actions replayed (env.step only in the timed region)",
-                    "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel)",
-                    "policy": "policy kernel + env.step per step",
-                    "random": "policy + env.step fused in one kernel per step"}[args.mode]
+            what = WHAT[args.mode] % args.fused_steps if args.mode == "random-fused" else WHAT[args.mode]
             out = {
                 "metric": "env_steps_per_sec", "value": value, "unit": "steps/s", "n_gpus": world,
                 "ranks_seen": ranks_seen, "steps": K, "warmup": W, "ms_per_step": launch_s * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u64",
                 "data": "synthetic",
                 "clock": "HIP events on the launch stream around the K launches; median of %d regions "
                          "(max over ranks); value, ms_per_step and roofline all use it" % R,
                 "regions": R, "host_wall_ms_per_step": wall_med * 1e3 / K, "returns_gather": gather,
                 "best_region_ms_per_step": ev_min * 1e3 / K,
-                "config": {"workload": "%d boards per GPU, uniform-legal random policy, auto-reset, %s" % (B, what),
-                           "boards_per_gpu": B, "boards_total": B * world, "state_bytes_per_board": state_bytes,
+                "config": {"workload": "%d boards %s, uniform-legal random policy, auto-reset, %s"
+                                       % (total if strong else B, "sharded over %d GPUs" % world if strong else "per GPU", what),
+                           "boards_per_gpu": B, "boards_total": total, "state_bytes_per_board": state_bytes,
                            "parallelism": "shard%d" % world, "mode": args.mode,
                            "dist_backend": backend if use_dist else None,
                            "self_launched": bool(os.environ.get("QTTT_BENCH_SELF_LAUNCHED")),
-                           "board_offset_last_rank": (world - 1) * B,
+                           "board_offset_last_rank": shard_range(total, world - 1, world)[0] if strong else (world - 1) * B,
                            "replay_matches_recording": replay_ok,
                            "episodes_finished": int(term_count), "steps_with_line": int(win_count)},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "traffic_source": None if traffic is None else PMC_SUMMARY,
-                             "kernel": kernel, "launch_us": launch_s * 1e6,
+                             "kernel": kernel_label(args.mode, bpl, blk), "launch_us": launch_s * 1e6,
                              "algorithmic_bytes_per_board_step": algo_bytes,
                              "algorithmic_bytes_per_launch": algo_bytes * B},
             }
+            actions = wl.actions
+            del wl
+            if world == 1 and not args.no_legs:
+                out["legs"] = run_legs(torch, dev, args)
             if not args.no_cpu_baseline and world == 1:                 # rank 0 at N = 1 only
-                # bounded sample: the first <=256 recorded steps of every board of rank 0, ~12 s of CPU
-                t_cpu = min(T, 256)
+                # bounded sample: the first <=256 recorded steps of every board of rank 0, ~15 s of CPU
+                t_cpu = min(K + W, 256)
                 out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed, args.cpu_budget)
             print(json.dumps(out), flush=True)
     if use_dist:
@@ -403,8 +573,9 @@ def run(args):
 
 def main():
     args = parse_args()
-    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.boards < 1:
-        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1")
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.boards < 1 or args.total_boards < 0 \
+            or args.fused_steps < 1 or (args.total_boards and args.total_boards < args.gpus):
+        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1, --total-boards >= --gpus")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # before anything imports torch or touches the GPU
     sys.exit(run(args))

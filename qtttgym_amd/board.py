@@ -7,9 +7,14 @@ Python objects because L3 callers subclass it and assign them directly (mcts.py:
 pinned host memory, run qttt_board_op (import -> the same step function the batch kernels use ->
 export + check_win, ONE kernel launch reading and writing the pinned records directly) and take the
 attributes back from the out record.  It is a compatibility surface, not a fast path (a launch and
-a synchronise per call): batch work belongs in `VecEnv`.
+a synchronise per call): batch work belongs in `VecEnv`, or — for reference-shaped objects —
+in `Board.make_moves`, which ships n records through one launch.
+
+Thread-safety: the pinned staging records are shared by every Board of the process and guarded by a lock;
+a Board object itself is a plain mutable Python object, as in the reference.
 """
 import random
+import threading
 
 import torch
 
@@ -57,18 +62,23 @@ class _Staging:
             raise _native.QtttNativeError("no HIP device visible (torch.cuda.is_available() is False); "
                                           "Board runs its rules in libqttt_hip.so, there is no CPU path")
         self.lib = _native.lib()
-        nb = _native.BOARD_RECORD_BYTES
+        self.lock = threading.Lock()
+        self.op_sync = self.lib.qttt_board_op_sync
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._alloc(64)
+
+    def _alloc(self, n_records):
+        nb = _native.BOARD_RECORD_BYTES * n_records
         self.t_in = torch.zeros(nb, dtype=torch.uint8).pin_memory()
         self.t_out = torch.zeros(nb, dtype=torch.uint8).pin_memory()
         self.a_in = self.t_in.numpy()          # plain memory views of the pinned buffers
         self.a_out = self.t_out.numpy()
         self.m_in = memoryview(self.a_in)
         self.p_in, self.p_out = self.t_in.data_ptr(), self.t_out.data_ptr()
-        self.op_sync = self.lib.qttt_board_op_sync
-        self.device = torch.device("cuda", torch.cuda.current_device())
 
-    def run(self, board, op, lo=0, hi=0, bit=0, drop_last_move=False):
-        """Ships board's attributes + the move, runs qttt_board_op, returns the out record."""
+    @staticmethod
+    def pack(board, op, lo=0, hi=0, bit=0, drop_last_move=False):
+        """board's attributes + the move as the first 41 bytes of a qttt_board_op record."""
         moves = board.moves[:-1] if drop_last_move else board.moves
         if len(moves) > 9:
             moves = moves[:9]
@@ -81,27 +91,46 @@ class _Staging:
             for x in qs[k]:
                 mask |= 1 << int(x)
             masks[k] = mask & 0xFFFF
-        # the record is built as one bytes object and lands in the pinned buffer with one copy
-        self.m_in[0:41] = (bytes([v & 255 for m in moves for v in (m[0], m[1])]) + _PAD18[2 * n:] + bytes([n])
-                           + bytes([x & 255 for x in board.board[:9]])
-                           + bytes([nq, op, masks[0] & 255, masks[0] >> 8, masks[1] & 255, masks[1] >> 8,
-                                    masks[2] & 255, masks[2] >> 8, masks[3] & 255, masks[3] >> 8,
-                                    lo & 255, hi & 255, bit & 255]))
+        return (bytes([v & 255 for m in moves for v in (m[0], m[1])]) + _PAD18[2 * n:] + bytes([n])
+                + bytes([x & 255 for x in board.board[:9]])
+                + bytes([nq, op, masks[0] & 255, masks[0] >> 8, masks[1] & 255, masks[1] >> 8,
+                         masks[2] & 255, masks[2] >> 8, masks[3] & 255, masks[3] >> 8,
+                         lo & 255, hi & 255, bit & 255]))
+
+    def run(self, board, op, lo=0, hi=0, bit=0, drop_last_move=False):
+        """Ships board's attributes + the move, runs qttt_board_op, returns the out record (bytes)."""
+        rec = self.pack(board, op, lo, hi, bit, drop_last_move)
+        with self.lock:                                    # one staging record per process: one caller at a time
+            # the record is built as one bytes object and lands in the pinned buffer with one copy
+            self.m_in[0:41] = rec
+            self._launch(1)
+            return self.a_out[:_native.BOARD_RECORD_BYTES].tobytes()
+
+    def run_many(self, records):
+        """n packed records (41 bytes each) -> n out records (64 bytes each), ONE launch and one synchronise."""
+        n = len(records)
+        nb = _native.BOARD_RECORD_BYTES
+        with self.lock:
+            if n * nb > self.t_in.numel():
+                self._alloc(max(n, 2 * (self.t_in.numel() // nb)))
+            self.m_in[0:n * nb] = b"".join(r + _PAD23 for r in records)
+            self._launch(n)
+            out = self.a_out[:n * nb].tobytes()
+        return [out[i * nb:(i + 1) * nb] for i in range(n)]
+
+    def _launch(self, n):
+        # launch + hipStreamSynchronize in one call, on the caller's current stream (raw handle)
         if torch.cuda.current_device() == self.device.index:
-            self._launch()
+            rc = self.op_sync(self.p_in, self.p_out, n, _raw_stream(self.device.index))
         else:
             with torch.cuda.device(self.device):
-                self._launch()
-        return self.a_out
-
-    def _launch(self):
-        # launch + hipStreamSynchronize in one call, on the caller's current stream (raw handle)
-        rc = self.op_sync(self.p_in, self.p_out, 1, _raw_stream(self.device.index))
+                rc = self.op_sync(self.p_in, self.p_out, n, _raw_stream(self.device.index))
         if rc:
             _native.check(rc, "qttt_board_op_sync")
 
 
 _PAD18 = b"\xff" * 18
+_PAD23 = b"\x00" * 23                                                              # 41 packed bytes -> a 64-byte record
 _I8 = tuple(x - 256 if x > 127 else x for x in range(256))                           # u8 -> i8
 _SQUARES = tuple(tuple(v for v in range(9) if m >> v & 1) for m in range(512))       # mask -> squares
 
@@ -125,8 +154,8 @@ class Board:
 
     # ------------------------------------------------------------------ device round trip
     def _adopt(self, o):
-        """Takes the attributes back from an out record."""
-        r = o.tobytes()                                    # one copy out of the pinned record
+        """Takes the attributes back from an out record (bytes)."""
+        r = o
         n = min(r[18], 9)
         self.moves = list(zip(r[0:2 * n:2], r[1:2 * n:2], range(n)))
         self.board[:] = [_I8[x] for x in r[19:28]]         # in place: env.py:71,82 aliasing
@@ -155,8 +184,9 @@ class Board:
         return b
 
     # ------------------------------------------------------------------ reference API
-    def make_move(self, move):
-        """board.py:9-25, same exceptions with the same messages, raised before any mutation."""
+    def _validate(self, move):
+        """board.py:10-18 + 28-42: raises what the reference raises (before any mutation), else returns
+        (lo, hi, closes_a_cycle, index of lo's component)."""
         if move[0] == move[1]:
             raise Exception("Move in same square not allowed when not necessary")
         if self.board[move[0]] != -1 or self.board[move[1]] != -1:   # IndexError for >8, as the list does
@@ -177,12 +207,53 @@ class Board:
             if hi in s:
                 m1 = j
                 break
-        if m0 == m1 and not isinstance(self.qeval, QEvalClassic):
+        return lo, hi, m0 == m1, m0
+
+    def make_move(self, move):
+        """board.py:9-25, same exceptions with the same messages, raised before any mutation."""
+        lo, hi, cycle, m0 = self._validate(move)
+        if cycle and not isinstance(self.qeval, QEvalClassic):
             return self._make_move_custom_eval(lo, hi, m0)
         bit = 0
-        if m0 == m1:
+        if cycle:
             bit = 1 if self.qeval.choose(lo, hi) == hi else 0
         self._make_move_device(lo, hi, bit)
+
+    @staticmethod
+    def make_moves(boards, moves, bits=None):
+        """n (board, move) pairs in ONE qttt_board_op launch and one synchronise: what an `_expand_child`-style
+        loop over a node's actions (mcts.py:210-221,233-267: copy the parent, make_move, 36 times) costs as
+        one round trip instead of 36.  Each board is mutated exactly as board.make_move(move) would.
+        bits: optional per-pair collapse choices (0 -> the closing move lands on min(a,b), 1 -> on max(a,b));
+        without them every cycle draws from its board's evaluator in order, as a loop of make_move would.
+        Returns a list with None where the move was made and the exception make_move would have raised
+        where it was not (that board is untouched)."""
+        n = len(boards)
+        if len(moves) != n or (bits is not None and len(bits) != n):
+            raise ValueError("boards, moves (and bits) must have the same length")
+        result = [None] * n
+        recs, idx = [], []
+        for i in range(n):
+            b = boards[i]
+            try:
+                lo, hi, cycle, m0 = b._validate(moves[i])
+            except Exception as e:                               # noqa: BLE001 — the reference raises bare Exception
+                if isinstance(e, _native.QtttNativeError):
+                    raise
+                result[i] = e
+                continue
+            if cycle and not isinstance(b.qeval, QEvalClassic):
+                b._make_move_custom_eval(lo, hi, m0)
+                continue
+            bit = 0
+            if cycle:
+                bit = (int(bits[i]) & 1) if bits is not None else (1 if b.qeval.choose(lo, hi) == hi else 0)
+            recs.append(_Staging.pack(b, _native.OP_MAKE_MOVE, lo, hi, bit))
+            idx.append(i)
+        if recs:
+            for i, o in zip(idx, _stage().run_many(recs)):
+                boards[i]._adopt(o)
+        return result
 
     def _make_move_custom_eval(self, lo, hi, m0, autofill=True):
         """Plug point board.py:2,7,51: a caller-supplied evaluator decides the collapse.  Its

@@ -25,7 +25,7 @@ def run_bench(*args, env=None):
 
 
 def test_bench_json_contract_small_batch():
-    d = run_bench("--boards", "65536", "--steps", "40", "--warmup", "5", "--cpu-budget", "2")
+    d = run_bench("--boards", "65536", "--steps", "40", "--warmup", "5", "--cpu-budget", "2", "--no-legs")
     for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline", "clock", "regions", "host_wall_ms_per_step"):
@@ -50,14 +50,22 @@ def test_bench_json_contract_small_batch():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "steps/s" and c["cores"] >= 1 and c["value"] > 1e6
     assert c["python_interpreter_steps_per_s"] > 1e4
+    # a one-thread figure, the box's nproc and CPU model beside the all-threads one
+    assert 1e6 < c["threads1"] <= c["value"] * 1.05 and c["nproc"] >= c["cores"] and isinstance(c["cpu_model"], str)
+    assert "legs" not in d
 
 
 def test_bench_modes_agree_on_the_episode_counters():
-    a = run_bench("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline")
-    b = run_bench("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--mode", "random")
-    c = run_bench("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--mode", "gym")
-    assert a["config"]["episodes_finished"] == b["config"]["episodes_finished"] == c["config"]["episodes_finished"] > 0
+    common = ("--boards", "16384", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-legs")
+    a = run_bench(*common)
+    b = run_bench(*common, "--mode", "random")
+    c = run_bench(*common, "--mode", "gym")
+    f = run_bench(*common, "--mode", "random-fused", "--fused-steps", "8")        # 30 steps = launches of 8 + 8 + 8 + 6
+    assert (a["config"]["episodes_finished"] == b["config"]["episodes_finished"] == c["config"]["episodes_finished"]
+            == f["config"]["episodes_finished"] > 0)
     assert b["config"]["replay_matches_recording"] is True and c["config"]["replay_matches_recording"] is True
+    assert f["config"]["replay_matches_recording"] is True and f["steps"] == 30
+    assert f["roofline"]["kernel"].startswith("step_random_fused_kernel")
     sb = c["config"]["state_bytes_per_board"]
     assert c["roofline"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7 + 30
 
@@ -78,16 +86,58 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert g["boards_gathered"] == 65536 and g["bytes_per_rank"] == 4 * 32768 and g["ms"] > 0
 
 
+def test_bench_default_line_carries_the_legs():
+    """the driver-run line itself carries the other BASELINE configurations and modes, measured
+    in the same process on the same clock, and the whole run stays short."""
+    import time
+    t0 = time.time()
+    d = run_bench("--steps", "20", "--warmup", "5", "--cpu-budget", "2")
+    assert time.time() - t0 < 120
+    assert d["config"]["boards_per_gpu"] == 1 << 20 and d["config"]["mode"] == "replay"
+    legs = {l["name"]: l for l in d["legs"]}
+    for name in ("config2_4096_boards", "config3_262144_boards", "beyond_infinity_cache_16777216_boards",
+                 "gym_1048576_boards", "random_1048576_boards", "random_fused_1048576_boards",
+                 "random_fused_262144_boards", "random_fused_4096_boards", "config5_expand_node_info_rollout_65536_boards"):
+        assert name in legs, name
+    for l in d["legs"]:
+        assert l["regions"] >= 5 and 0 < l["frac"] < 1 and l["achieved_GBps"] > 0
+        if "us_per_step" in l:
+            assert l["replay_matches_recording"] is True, l["name"]
+            assert abs(l["steps_per_s"] - l["boards"] / (l["us_per_step"] * 1e-6)) / l["steps_per_s"] < 1e-9
+    sb = d["config"]["state_bytes_per_board"]
+    assert legs["beyond_infinity_cache_16777216_boards"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7
+    assert 16777216 * (2 * sb) > 256 << 20                                     # the state alone exceeds the Infinity Cache
+    assert legs["gym_1048576_boards"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7 + 30
+    f = legs["random_fused_262144_boards"]
+    assert f["bound"] == "valu" and f["steps_per_launch"] == 64 and f["us_per_step"] < legs["config3_262144_boards"]["us_per_step"]
+
+
+def test_bench_total_boards_is_strong_scaling():
+    """BASELINE config 4's shape: a fixed total sharded over the ranks (here 2 ranks on the one GPU over gloo,
+    an odd total so the shards differ by one board)."""
+    d = run_bench("--gpus", "2", "--total-boards", "65537", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                  env={"QTTT_DIST_BACKEND": "gloo"})
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 == d["ranks_seen"]
+    assert d["config"]["boards_total"] == 65537 and d["config"]["boards_per_gpu"] == 32769
+    assert d["config"]["board_offset_last_rank"] == 32769
+    assert d["config"]["replay_matches_recording"] is True
+    assert abs(d["value"] - 65537 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    assert d["returns_gather"]["boards_gathered"] == 65537
+    one = run_bench("--total-boards", "65537", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs")
+    assert one["scaling"] == "strong" and one["config"]["boards_per_gpu"] == 65537
+    assert one["config"]["episodes_finished"] == d["config"]["episodes_finished"]     # the same boards, whatever the sharding
+
+
 def test_bench_rccl_branch_with_one_rank():
     """The N > 1 code path on the real backend: process group on RCCL ("nccl"), device barrier,
     all_reduce of the clock / the rank count / the episode counters, the returns gather — with the
     one rank a one-GPU box can give it (two ranks on one GPU are refused by RCCL itself)."""
-    d = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+    d = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs",
                   env={"QTTT_DIST_FORCE": "1", "QTTT_DIST_BACKEND": "nccl"})
     assert d["n_gpus"] == 1 == d["ranks_seen"] and d["config"]["dist_backend"] == "nccl"
     assert d["returns_gather"]["backend"] == "nccl" and d["returns_gather"]["boards_gathered"] == 65536
     assert d["config"]["replay_matches_recording"] is True
-    e = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    e = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs")
     assert e["config"]["dist_backend"] is None and e["returns_gather"] is None
     assert e["config"]["episodes_finished"] == d["config"]["episodes_finished"]
 

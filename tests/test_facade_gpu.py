@@ -251,3 +251,103 @@ def test_board_op_batches_records(golden):
         assert np.array_equal(o[:, 44:48].copy().view("<u4")[:, 0], g["reward"][:E, t].astype(np.float32).view(np.uint32)), t
         assert np.array_equal(o[:, 48], g["terminated"][:E, t]), t
         assert np.array_equal(o[:, 49].view(np.int8), g["p1_round"][:E, t]) and np.array_equal(o[:, 50].view(np.int8), g["p2_round"][:E, t]), t
+
+
+# ---------------------------------------------------------------------------------------------------
+# The reference's MCTS expansion through the façade (mcts.py:9-17, 233-267): a GameState(Board) subclass
+# gets its parent's attributes assigned, make_move is called with the bit source, and the result is held
+# against the children the reference's own mcts.py produced (tests/golden/expand_traces.npz).
+IND2MOVE = [(i, j) for i in range(9) for j in range(i + 1, 9)]          # mcts.py:339-343
+
+
+def _game_state_class():
+    from qtttgym_amd import Board, QEvalClassic
+
+    class GameState(Board):                                             # mcts.py:9-17
+        def __init__(self, board, moves, qstructs):
+            Board.__init__(self, QEvalClassic())
+            self.board = board
+            self.moves = moves
+            self.qstructs = qstructs
+    return GameState
+
+
+def _parent_attrs(gx, p):
+    nm, nq = int(gx["p_n_moves"][p]), int(gx["p_n_q"][p])
+    board = [int(x) for x in gx["p_board"][p]]
+    moves = [(int(gx["p_moves"][p, i, 0]), int(gx["p_moves"][p, i, 1]), i) for i in range(nm)]
+    qstructs = [set(s for s in range(9) if int(gx["p_qmask"][p, k]) >> s & 1) for k in range(nq)]
+    return board, moves, qstructs
+
+
+def _assert_child(gs, gx, k, c):
+    nm, nq = int(gx["c_n_moves"][k, c]), int(gx["c_n_q"][k, c])
+    assert gs.board == [int(x) for x in gx["c_board"][k, c]], (k, c)
+    assert gs.moves == [(int(gx["c_moves"][k, c, i, 0]), int(gx["c_moves"][k, c, i, 1]), i) for i in range(nm)], (k, c)
+    assert gs.qstructs == [set(s for s in range(9) if int(gx["c_qmask"][k, c, q]) >> s & 1) for q in range(nq)], (k, c)
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with np.load(os.path.join(root, "tests", "golden", "expand_traces.npz")) as d:
+        return {k: d[k] for k in d.files}
+
+
+def test_expand_traces_through_a_gamestate_subclass_one_make_move_at_a_time(gx, bits):
+    GameState = _game_state_class()
+    picks = range(0, len(gx["action"]), 3)                              # every third pair: 3 120 expansions
+    for k in picks:
+        p, a, nch = int(gx["parent"][k]), int(gx["action"][k]), int(gx["n_children"][k])
+        for c in range(max(nch, 1)):
+            gs = GameState(*_parent_attrs(gx, p))
+            bits.bit = c                                                # child c = the closing move on min / max
+            calls = bits.calls
+            if nch == 0:
+                with pytest.raises(Exception):
+                    gs.make_move(IND2MOVE[a])
+                assert (gs.board, gs.moves, gs.qstructs) == _parent_attrs(gx, p)
+            else:
+                gs.make_move(IND2MOVE[a])
+                assert bits.calls - calls == (1 if nch == 2 else 0)    # one draw per collapse (qeval.py:35)
+                _assert_child(gs, gx, k, c)
+
+
+def test_expand_traces_through_board_make_moves_in_one_launch(gx):
+    """All 9 360 (parent, action) pairs x both collapse choices as TWO batched calls of Board.make_moves."""
+    from qtttgym_amd import Board
+    GameState = _game_state_class()
+    n = len(gx["action"])
+    moves = [IND2MOVE[int(a)] for a in gx["action"]]
+    for c in range(2):
+        kids = [GameState(*_parent_attrs(gx, int(gx["parent"][k]))) for k in range(n)]
+        res = Board.make_moves(kids, moves, bits=[c] * n)
+        for k in range(n):
+            nch = int(gx["n_children"][k])
+            if nch == 0:
+                assert isinstance(res[k], Exception) and str(res[k]) == "Move in classical square not allowed", k
+                assert (kids[k].board, kids[k].moves, kids[k].qstructs) == _parent_attrs(gx, int(gx["parent"][k]))
+            else:
+                assert res[k] is None, (k, res[k])
+                _assert_child(kids[k], gx, k, c if nch == 2 else 0)
+
+
+def test_make_moves_draws_like_a_loop_of_make_move_and_reports_each_exception(bits):
+    from qtttgym_amd import Board, QEvalClassic
+    mk = lambda: Board(QEvalClassic())
+    a, b, c, d = mk(), mk(), mk(), mk()
+    for x in (a, b):
+        x.make_move((0, 1))
+    bits.bit = 1
+    calls = bits.calls
+    res = Board.make_moves([a, b, c, d], [(1, 0), (0, 2), (4, 4), (3, 9)])
+    assert bits.calls - calls == 1                                      # only a's move closes a cycle
+    assert res[0] is None and a.board[:2] == [0, 1] and a.moves == [(0, 1, 0), (0, 1, 1)] and a.qstructs == []
+    assert res[1] is None and b.moves == [(0, 1, 0), (0, 2, 1)] and b.qstructs == [{0, 1, 2}]
+    assert str(res[2]) == "Move in same square not allowed when not necessary" and c.moves == []
+    assert isinstance(res[3], IndexError) and d.moves == []
+    assert a.check_win() == (-1, -1)
+    with pytest.raises(ValueError):
+        Board.make_moves([a], [(2, 3), (4, 5)])
+    assert Board.make_moves([], []) == []

@@ -45,7 +45,33 @@ def main():
         b2 = Board(QEvalClassic())
         b2.make_move((i % 8, 8))
     t_mm = (time.perf_counter() - t0) / n
+    # an _expand_child-style loop (mcts.py:210-221): 36 copies of a parent, one move each — one make_move at a
+    # time, and as ONE Board.make_moves call
+    pairs = [(i, j) for i in range(9) for j in range(i + 1, 9)]
+    parent = Board(QEvalClassic())
+    parent.make_move((0, 1))
+    parent.make_move((1, 2))
+
+    def copies():
+        out = []
+        for _ in pairs:
+            k = Board(QEvalClassic())
+            k.board, k.moves, k.qstructs = parent.board.copy(), parent.moves.copy(), [set(q) for q in parent.qstructs]
+            out.append(k)
+        return out
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for k, mv in zip(copies(), pairs):
+            k.make_move(mv)
+    t_loop = (time.perf_counter() - t0) / (reps * len(pairs))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        Board.make_moves(copies(), pairs)
+    t_batch = (time.perf_counter() - t0) / (reps * len(pairs))
     print(json.dumps({"row": "facade_latency_N1", "Env.step_us": t_env * 1e6, "Board.make_move_us": t_mm * 1e6,
+                      "expand_36_children_loop_of_make_move_us_per_child": t_loop * 1e6,
+                      "expand_36_children_one_make_moves_call_us_per_child": t_batch * 1e6,
                       "Board.check_win_us": t_cw * 1e6, "reference_Env.step_us": 12.0,
                       "note": "Env.step = one qttt_board_op launch + one stream synchronise (check_win comes back in the same record); the loop also pays the random legal move and Env.reset of each episode"}))
 

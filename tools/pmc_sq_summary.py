@@ -30,7 +30,7 @@ def main():
     w.writerow(["kernel", "dispatches"] + counters + ["SQ_INSTS_VALU_per_board"])
     ours = ("step_kernel", "sample_actions_kernel", "observe_kernel", "check_win_kernel", "export_kernel",
             "import_kernel", "node_info_kernel", "expand_kernel", "rollout_kernel", "encode_kernel", "board_op_kernel",
-            "step_fused_kernel", "floor")
+            "step_fused_kernel", "step_random_fused_kernel", "floor")
     for k in sorted(acc):
         if not any(o in k for o in ours):
             continue                                   # torch's own reductions / copies of the recording pass
@@ -38,7 +38,7 @@ def main():
         n = max(len(x) for x in v.values())
         row = [k, n] + ["%.1f" % (sum(v[c]) / len(v[c])) if c in v else "" for c in counters]
         per = ""
-        if "step_kernel" in k and "SQ_INSTS_VALU" in v:
+        if ("step_kernel" in k or "step_random_fused_kernel" in k) and "SQ_INSTS_VALU" in v:
             per = "%.1f" % (sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) * 64.0 / boards)
         w.writerow(row + [per])
 
