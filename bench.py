@@ -225,7 +225,11 @@ def median(xs):
 
 
 # ---------------------------------------------------------------------------- one workload, one clock
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0   # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz, 4 cycles each
+# wave64 VALU instructions per ns the chip can issue at best: 1 024 SIMDs x one instruction per 1.03 ns, the measured
+# rate of the FAST class (plain logic, add / sub, right shifts; profiles/r02/valu_rates.txt).  Everything else (left
+# shifts, bfe, compares, selects, multiplies, anything with an SGPR operand) issues at 1.7x that, so a real mix tops out
+# well below 1.0 of this peak.
+VALU_PEAK_GINST = 1024 / 1.03
 
 
 def kernel_label(mode, bpl, blk):
@@ -359,10 +363,11 @@ def run_legs(torch, dev, args):
                "frac": w.algo_bytes * B / (ev / K) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
                "replay_matches_recording": w.replay_ok}
         if mode == "random-fused":
-            # VALU-bound (the boards never leave the registers): SQ_INSTS_VALU per board-step from
-            # profiles/r03/pmc_sq_fused_summary.csv against the chip's wave-instruction issue rate
+            # VALU-bound (the boards never leave the registers): SQ_INSTS_VALU per board-step (a committed PMC
+            # figure, not measured in this run) against the chip's best wave-instruction issue rate
             leg.update(bound="valu", steps_per_launch=min(fused_T, K), us_per_launch=us * min(fused_T, K),
-                       valu_insts_per_board_step=FUSED_VALU_PER_STEP,
+                       valu_insts_per_board_step=FUSED_VALU_PER_STEP, valu_source="profiles/r03/pmc_sq_fused_summary.csv",
+                       valu_peak_ginst_per_s=VALU_PEAK_GINST,
                        valu_frac=None if FUSED_VALU_PER_STEP is None else
                        FUSED_VALU_PER_STEP * (B / 64.0) / (ev / K * 1e9) / VALU_PEAK_GINST)
         else:
@@ -383,7 +388,9 @@ def run_legs(torch, dev, args):
     return legs
 
 
-FUSED_VALU_PER_STEP = None   # set from profiles/ once measured (tools/pmc_sq_summary.py)
+# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 155 547 054 per dispatch of 1 048 576 boards x
+# 64 steps = 9 493.8 per wave = 148.3 per ply (profiles/r03/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass)
+FUSED_VALU_PER_STEP = 148.3
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):
