@@ -205,12 +205,18 @@ typedef struct qttt_env {
     uint8_t *terminated;            /* u8[n] */
     int8_t  *classical;             /* the qttt_observe outputs; only read by QTTT_ENV_STEP_OBSERVE */
     uint8_t *q_p1, *q_p1_len, *q_p2, *q_p2_len, *turn;
+    const uint32_t *step_counter;   /* nullable DEVICE u32: the step index a launch uses is step_idx + *step_counter,
+                                       read when the kernel runs — so qttt_env_step calls captured in a hipGraph can be
+                                       replayed (a graph node cannot carry a host-side step counter): capture node t with
+                                       step_idx = t and end the graph with qttt_counter_add(step_counter, T) */
 } qttt_env;
 #define QTTT_ENV_STEP         0     /* = qttt_step(actions, bits) */
 #define QTTT_ENV_STEP_OBSERVE 1     /* = qttt_step_observe(actions, bits) */
 #define QTTT_ENV_STEP_RANDOM  2     /* = qttt_step_random(actions_out = actions, nullable); bits ignored */
 int qttt_env_step(const qttt_env *env, uint8_t *actions, const uint8_t *bits, uint32_t step_idx,
                   int mode, void *stream);
+/* *counter += by, on the stream (one lane): advances a qttt_env.step_counter; capturable like every other entry */
+int qttt_counter_add(uint32_t *counter, uint32_t by, void *stream);
 
 /* Process-wide DEFAULT launch shape of qttt_step / qttt_step_observe / qttt_step_random (results never
  * depend on it): boards per lane (1, 2 or 4) and workgroup size (256, 512 or 1024); 0 = chosen by the

@@ -19,7 +19,7 @@ class EnvRecord(ctypes.Structure):
                 ("seed", ctypes.c_uint64), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
                 ("reward", ctypes.c_void_p), ("terminated", ctypes.c_void_p), ("classical", ctypes.c_void_p),
                 ("q_p1", ctypes.c_void_p), ("q_p1_len", ctypes.c_void_p), ("q_p2", ctypes.c_void_p),
-                ("q_p2_len", ctypes.c_void_p), ("turn", ctypes.c_void_p)]
+                ("q_p2_len", ctypes.c_void_p), ("turn", ctypes.c_void_p), ("step_counter", ctypes.c_void_p)]
 
 
 ENV_STEP, ENV_STEP_OBSERVE, ENV_STEP_RANDOM = 0, 1, 2
@@ -50,6 +50,7 @@ SIGNATURES = {
     "qttt_set_tuning": (_i32, [_i32, _i32]),
     "qttt_step_launch_shape": (_i32, [_i64, _u32, _i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "qttt_env_step": (_i32, [ctypes.POINTER(EnvRecord), _vp, _vp, _u32, _i32, _vp]),
+    "qttt_counter_add": (_i32, [_vp, _u32, _vp]),
     "qttt_step_random": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _vp]),
     "qttt_hash": (_u64, [_u64, _u64, _u32]),
 }

@@ -409,6 +409,9 @@ __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     }
 }
 
+// the device-side step counter of qttt_env.step_counter, advanced on the stream (one lane)
+__global__ void counter_add_kernel(u32 *counter, u32 by) { *counter += by; }
+
 }  // namespace
 
 #endif  // QTTT_AUX_KERNELS_H

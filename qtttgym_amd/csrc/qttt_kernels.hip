@@ -165,13 +165,15 @@ int qttt_reset(void *state, int64_t n, void *stream) {
 
 static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint64_t seed,
                        uint32_t step_idx, int64_t board_offset, uint32_t flags, float *reward,
-                       uint8_t *terminated, int64_t n, void *stream, bool sample, const ObsOut *obs) {
+                       uint8_t *terminated, int64_t n, void *stream, bool sample, const ObsOut *obs,
+                       const uint32_t *step_ctr = nullptr) {
     if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state || !reward || !terminated || (!sample && !actions)) return QTTT_ERR_NULL;
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are accessed as u16 pairs
     Planes p = planes(state, n);
-    const u64 key = launch_key(seed, step_idx);
+    // with a device-side step counter the kernel makes the key itself: it gets the offset and the id fold
+    const u64 key = step_ctr ? ((u64)step_idx << 32) : launch_key(seed, step_idx);
     const u32 key_lo = (u32)key, key_hi = (u32)(key >> 32);
     hipStream_t s = (hipStream_t)stream;
     uint16_t *a16 = reinterpret_cast<uint16_t *>(actions);
@@ -189,7 +191,7 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
 #define QTTT_LAUNCH_B(BLK, BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                        \
     hipLaunchKernelGGL((step_kernel<BLK, BPL, HB, AR, SM, OB>), dim3(blocks_for(NG, BLK)), dim3(BLK), 0, s, \
                        p.P, p.Q, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated, oo,         \
-                       (int64_t)(I0), (u32)((NG) - (int64_t)(blocks_for(NG, BLK) - 1) * (BLK)))
+                       (int64_t)(I0), (u32)((NG) - (int64_t)(blocks_for(NG, BLK) - 1) * (BLK)), StepKeySource<false>{})
     // workgroup size as chosen above; four boards per lane exists with 512 threads only
 #define QTTT_LAUNCH(BPL, HB, AR, SM, OB, I0, NG, KF, IDB)                                              \
     do {                                                                                              \
@@ -207,6 +209,19 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
         else if (bits) { if (ar) QTTT_LAUNCH(BPL, true, true, false, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, true, false, false, false, I0, NG, KF, IDB); } \
         else { if (ar) QTTT_LAUNCH(BPL, false, true, false, false, I0, NG, KF, IDB); else QTTT_LAUNCH(BPL, false, false, false, false, I0, NG, KF, IDB); } \
     } while (0)
+    // Device-side step counter (graph capture: small, launch-bound batches): one launch shape — one board per
+    // lane, 256-thread workgroups — and the kernels that make the launch key themselves.
+    const StepKeySource<true> sk = {step_ctr, (u64)seed};
+#define QTTT_LAUNCH_DEV(AR, SM, OB, I0, NG, KF, IDB)                                                    \
+    hipLaunchKernelGGL((step_kernel<256, 1, false, AR, SM, OB, true>), dim3(blocks_for(NG, 256)), dim3(256), 0, s, \
+                       p.P, p.Q, a16, bits, (u32)(KF), key_hi, (u32)(IDB), rb, terminated, oo,         \
+                       (int64_t)(I0), (u32)((NG) - (int64_t)(blocks_for(NG, 256) - 1) * 256), sk)
+#define QTTT_DISPATCH_DEV(I0, NG, KF, IDB)                                                            \
+    do {                                                                                              \
+        if (obs) { if (ar) QTTT_LAUNCH_DEV(true, false, true, I0, NG, KF, IDB); else QTTT_LAUNCH_DEV(false, false, true, I0, NG, KF, IDB); } \
+        else if (sample) { if (ar) QTTT_LAUNCH_DEV(true, true, false, I0, NG, KF, IDB); else QTTT_LAUNCH_DEV(false, true, false, I0, NG, KF, IDB); } \
+        else { if (ar) QTTT_LAUNCH_DEV(true, false, false, I0, NG, KF, IDB); else QTTT_LAUNCH_DEV(false, false, false, I0, NG, KF, IDB); } \
+    } while (0)
     // The hash folds the global board id as lo32 ^ hi32*C (fold_id).  hi32 is uniform over a
     // range of boards unless the range crosses a multiple of 2^32; the batch is cut there (at most
     // once), so the kernel only ever adds a lane index to a 32-bit base.
@@ -217,6 +232,11 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
         const int64_t seg_n = (int64_t)((u64)(n - seg_begin) < to_boundary ? (u64)(n - seg_begin) : to_boundary);
         const u32 key_fold = key_lo ^ ((u32)(first >> 32) * 0x9E3779B9u);
         const u32 id_base = (u32)first;
+        if (step_ctr && !bits) {                                 // (explicit bits need no key: the ordinary kernels do)
+            QTTT_DISPATCH_DEV(seg_begin, seg_n, key_fold, id_base);
+            seg_begin += seg_n;
+            continue;
+        }
         int bpl = bpl_max;
         while (bpl > 1 && (seg_begin % bpl) != 0) bpl >>= 1;     // vector accesses need an aligned start
         const int64_t n_groups = seg_n / bpl, n_main = n_groups * bpl;
@@ -229,6 +249,8 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
             QTTT_DISPATCH(1, seg_begin + n_main, seg_n - n_main, key_fold, id_base + (u32)n_main);
         seg_begin += seg_n;
     }
+#undef QTTT_DISPATCH_DEV
+#undef QTTT_LAUNCH_DEV
 #undef QTTT_DISPATCH
 #undef QTTT_LAUNCH
 #undef QTTT_LAUNCH_B
@@ -265,18 +287,27 @@ int qttt_env_step(const qttt_env *e, uint8_t *actions, const uint8_t *bits, uint
     if (!e) return QTTT_ERR_NULL;
     switch (mode) {
     case QTTT_ENV_STEP:
-        return qttt_step(e->state, actions, bits, e->seed, step_idx, e->board_offset, e->flags, e->reward,
-                         e->terminated, e->n, stream);
-    case QTTT_ENV_STEP_OBSERVE:
-        return qttt_step_observe(e->state, actions, bits, e->seed, step_idx, e->board_offset, e->flags, e->reward,
-                                 e->terminated, e->classical, e->q_p1, e->q_p1_len, e->q_p2, e->q_p2_len, e->turn,
-                                 e->n, stream);
+        return launch_step(e->state, actions, bits, e->seed, step_idx, e->board_offset, e->flags, e->reward,
+                           e->terminated, e->n, stream, false, nullptr, e->step_counter);
+    case QTTT_ENV_STEP_OBSERVE: {
+        if (e->n > 0 && (!e->classical || !e->q_p1 || !e->q_p1_len || !e->q_p2 || !e->q_p2_len || !e->turn)) return QTTT_ERR_NULL;
+        if (((uintptr_t)e->q_p1 & 1u) || ((uintptr_t)e->q_p2 & 7u)) return QTTT_ERR_ACTION;
+        const ObsOut o = {e->classical, e->q_p1, e->q_p1_len, e->q_p2, e->q_p2_len, e->turn};
+        return launch_step(e->state, actions, bits, e->seed, step_idx, e->board_offset, e->flags, e->reward,
+                           e->terminated, e->n, stream, false, &o, e->step_counter);
+    }
     case QTTT_ENV_STEP_RANDOM:
-        return qttt_step_random(e->state, e->seed, step_idx, e->board_offset, e->flags, actions, e->reward,
-                                e->terminated, e->n, stream);
+        return launch_step(e->state, actions, nullptr, e->seed, step_idx, e->board_offset, e->flags, e->reward,
+                           e->terminated, e->n, stream, true, nullptr, e->step_counter);
     default:
         return QTTT_ERR_SIZE;
     }
+}
+
+int qttt_counter_add(uint32_t *counter, uint32_t by, void *stream) {
+    if (!counter) return QTTT_ERR_NULL;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, by);
+    return launch_status();
 }
 
 int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uint64_t seed,

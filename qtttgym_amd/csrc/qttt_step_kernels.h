@@ -20,12 +20,23 @@ namespace {
 // (auto_tuning() in qttt_kernels.hip holds the measured table: one board per lane in 256-thread
 // workgroups below ~450 K boards, 1024-thread workgroups where they fill the chip exactly once,
 // two boards per lane in 256-thread workgroups above 1 536 K boards).
-template <int BLOCK, int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false>
+// DEVSTEP: the step index lives on the DEVICE (qttt_env.step_counter, for launches captured in a hipGraph: the
+// host cannot bake a step index into a node that is replayed).  key_hi then carries the node's offset, key_fold
+// the fold of the ids' high word, and the launch key is made in the kernel (scalar unit, ~30 SALU instructions).
+// A separate instantiation, so that the kernels of the ordinary path carry neither the two extra arguments nor
+// the branch (measured: 2-3 % on a 1 M-board launch when they did).
+template <bool DEVSTEP> struct StepKeySource {};
+template <> struct StepKeySource<true> {
+    const u32 *ctr;
+    u64 seed;
+};
+
+template <int BLOCK, int BPL, bool HAS_BITS, bool AUTO_RESET, bool SAMPLE = false, bool OBS = false, bool DEVSTEP = false>
 __global__ __launch_bounds__(BLOCK) void step_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, uint16_t *__restrict__ actions,
     const uint8_t *__restrict__ bits, u32 key_fold, u32 key_hi, u32 id_base,
     u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, ObsOut obs, int64_t i_begin,
-    u32 last_groups) {
+    u32 last_groups, StepKeySource<DEVSTEP> sk) {
     constexpr u32 TILE_BOARDS = BLOCK * BPL;
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
@@ -38,6 +49,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     typedef Vec<u32, BPL> V32;
     typedef Vec<uint16_t, BPL> V16;
     typedef Vec<uint8_t, BPL> V8;
+    if constexpr (DEVSTEP) {
+        const u64 key = launch_key(sk.seed, key_hi + *sk.ctr);
+        key_fold ^= (u32)key;
+        key_hi = (u32)(key >> 32);
+    }
     const int64_t jb = (int64_t)blockIdx.x * BLOCK;                // first lane-group of the block
     const int64_t ib = i_begin + jb * BPL;                              // first board of the block
     // lane-groups of this block: every block is full except possibly the last one of the grid

@@ -51,7 +51,7 @@ class VecEnv:
         self.seed = int(seed)
         self.auto_reset = bool(auto_reset)
         self.board_offset = int(board_offset)     # global index of board 0 (multi-GPU shards)
-        self.step_idx = 0
+        self._step_host, self._ctr = 0, None      # the step index: a host int, or (graph mode) a device u32
         # (boards per lane, workgroup size) of this environment's step launches, carried by every call's
         # flags (QTTT_FLAG_SHAPE); None = the library picks it from the batch size.  Never changes results.
         self._shape_flags = _native.flag_shape(*launch_shape) if launch_shape else 0
@@ -66,6 +66,38 @@ class VecEnv:
         self._obs = None
         self._bind_outputs()
         self.reset()
+
+    # ------------------------------------------------------------------ the step index
+    @property
+    def step_idx(self):
+        """Steps taken since reset: keys the collapse-bit / policy hash.  A host int — or, once
+        use_device_step_counter() / capture() was called, a device-side u32 (reading it then synchronises)."""
+        return self._step_host + (0 if self._ctr is None else int(self._ctr))
+
+    @step_idx.setter
+    def step_idx(self, v):
+        if self._ctr is None:
+            self._step_host = int(v)
+        else:
+            self._step_host = 0
+            self._ctr.fill_(int(v))
+
+    def use_device_step_counter(self):
+        """Moves the step index into a device-side u32 that the step kernels read when they RUN
+        (qttt_env.step_counter): launches captured in a hipGraph then use a fresh index on every replay.
+        Eager calls keep working; each of them advances the counter with one extra one-lane launch."""
+        if self._ctr is None:
+            with torch.cuda.device(self.device):
+                self._ctr = torch.tensor(self._step_host, dtype=torch.int32, device=self.device)
+            self._step_host = 0
+            self._rec.step_counter = self._ctr.data_ptr()
+        return self._ctr
+
+    def _advance(self, k):
+        if self._ctr is None:
+            self._step_host += k
+        else:
+            _native.check(self._launch(self._lib.qttt_counter_add, self._ctr.data_ptr(), k, self._stream()), "qttt_counter_add")
 
     # ------------------------------------------------------------------ helpers
     def _bind_outputs(self):
@@ -119,7 +151,7 @@ class VecEnv:
         """Fresh boards without building the observation (one memset on the stream)."""
         if seed is not None:
             self.seed = int(seed)
-        self.step_idx = 0
+        self.step_idx = 0                         # (the device counter's fill is ordered on the stream like the memset)
         with torch.cuda.device(self.device):
             _native.check(self._lib.qttt_reset(self.state.data_ptr(), self.num_envs, self._stream()),
                           "qttt_reset")
@@ -142,11 +174,11 @@ class VecEnv:
         if bits is not None and (bits.dtype != torch.uint8 or not bits.is_contiguous()
                                  or bits.device != self.state.device or bits.numel() != n):
             raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
-        rc = self._launch(self._env_step, self._record(), actions.data_ptr(), _ptr(bits), self.step_idx,
+        rc = self._launch(self._env_step, self._record(), actions.data_ptr(), _ptr(bits), self._step_host,
                           _native.ENV_STEP, self._stream())
         if rc:
             _native.check(rc, "qttt_step")
-        self.step_idx += 1
+        self._advance(1)
         return self._reward, self._terminated
 
     def step_random(self, actions_out=None):
@@ -157,11 +189,11 @@ class VecEnv:
         if actions_out is not None and (actions_out.dtype != torch.uint8 or not actions_out.is_contiguous()
                                         or actions_out.numel() != 2 * n or actions_out.device != self.state.device):
             raise ValueError("actions_out must be a contiguous uint8 device tensor of shape (N, 2)")
-        rc = self._launch(self._env_step, self._record(), _ptr(actions_out), None, self.step_idx,
+        rc = self._launch(self._env_step, self._record(), _ptr(actions_out), None, self._step_host,
                           _native.ENV_STEP_RANDOM, self._stream())
         if rc:
             _native.check(rc, "qttt_step_random")
-        self.step_idx += 1
+        self._advance(1)
         return self._reward, self._terminated
 
     def step_many(self, actions, bits=None, reward=None, terminated=None, fused=False):
@@ -192,7 +224,7 @@ class VecEnv:
                                           self._flags() | (_native.FLAG_FUSED if fused else 0), r.data_ptr(),
                                           tm.data_ptr(), stride, n, T, self._stream())
         _native.check(rc, "qttt_step_many")
-        self.step_idx += T
+        self._advance(T)
         return r, tm
 
     def step(self, actions, bits=None, verbose=False, copy_obs=True):
@@ -246,11 +278,11 @@ class VecEnv:
                                  or bits.device != self.state.device or bits.numel() != n):
             raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
         o = self._obs_buffers()
-        rc = self._launch(self._env_step, self._record(), actions.data_ptr(), _ptr(bits), self.step_idx,
+        rc = self._launch(self._env_step, self._record(), actions.data_ptr(), _ptr(bits), self._step_host,
                           _native.ENV_STEP_OBSERVE, self._stream())
         if rc:
             _native.check(rc, "qttt_step_observe")
-        self.step_idx += 1
+        self._advance(1)
         return o, self._reward, self._terminated
 
     def observ(self):
@@ -375,7 +407,7 @@ class VecEnv:
                           self.board_offset, self._flags(), _ptr(actions_out), r.data_ptr(), tm.data_ptr(), stride, n, T,
                           self._stream())
         _native.check(rc, "qttt_step_random_many")
-        self.step_idx += T
+        self._advance(T)
         return r, tm
 
     # ------------------------------------------------------------------ MCTS-side rows
@@ -388,7 +420,8 @@ class VecEnv:
         env._lib = _native.lib()
         if state.dtype != torch.uint8 or state.numel() != env._lib.qttt_state_bytes(env.num_envs):
             raise ValueError("state must be a uint8 tensor of qttt_state_bytes(num_envs) bytes")
-        env.seed, env.auto_reset, env.board_offset, env.step_idx = int(seed), bool(auto_reset), int(board_offset), 0
+        env.seed, env.auto_reset, env.board_offset = int(seed), bool(auto_reset), int(board_offset)
+        env._step_host, env._ctr = 0, None
         env._shape_flags = 0
         env.action_space = reference_action_space()
         env.observation_space = reference_observation_space()
@@ -504,6 +537,83 @@ class VecEnv:
         _native.check(rc, "qttt_encode")
         return (vec, mask) if with_mask else vec
 
+    # ------------------------------------------------------------------ hipGraph of T step launches
+    def capture(self, n_steps, mode="random", actions=None, bits=None, actions_out=None, reward=None, terminated=None):
+        """Captures n_steps step LAUNCHES into one hipGraph and returns it (`.replay()`): for loops on small
+        batches, where one launch per step is host-bound (4-5 us per call against a ~3 us kernel at <= 262 144
+        boards) and the policy must see the state every step, so the fused multi-step kernels do not apply.
+        mode "random": step_random() x n_steps (actions_out u8[T,N,2] optional);
+        mode "step" / "observe": step_raw / step_observe_raw reading actions u8[T,N,2] (bits u8[T,N] optional) —
+        the caller's buffers, refilled between replays (e.g. by a policy network captured in its own graph).
+        reward f32[T,N] + terminated bool[T,N] keep every step's outputs; without them the environment's own
+        buffers hold the last step's.  The step index lives on the device from here on
+        (use_device_step_counter), so every replay draws fresh collapse bits; the graph ends by advancing it."""
+        T, n, dev = int(n_steps), self.num_envs, self.state.device
+        if mode not in ("random", "step", "observe") or T < 1:
+            raise ValueError("mode must be 'random', 'step' or 'observe' and n_steps >= 1")
+        if mode == "random":
+            if actions is not None or bits is not None:
+                raise ValueError("mode 'random' draws its own actions (actions_out receives them)")
+            if actions_out is not None:
+                _check_out(actions_out, torch.uint8, (T, n, 2), dev, "actions_out")
+        else:
+            if actions is None or actions_out is not None:
+                raise ValueError("mode %r reads actions u8[T,N,2]" % mode)
+            _check_out(actions, torch.uint8, (T, n, 2), dev, "actions")
+            if bits is not None:
+                _check_out(bits, torch.uint8, (T, n), dev, "bits")
+        if (reward is None) != (terminated is None):
+            raise ValueError("reward f32[T,N] and terminated bool[T,N] must be given together")
+        if reward is not None:
+            _check_out(reward, torch.float32, (T, n), dev, "reward")
+            _check_out(terminated, torch.bool, (T, n), dev, "terminated")
+        if mode == "observe":
+            self._obs_buffers()
+        ctr = self.use_device_step_counter()
+        self._record()
+        code = {"random": _native.ENV_STEP_RANDOM, "step": _native.ENV_STEP, "observe": _native.ENV_STEP_OBSERVE}[mode]
+        recs = []
+        for t in range(T):                     # one record per node: its own slice of the per-step outputs
+            r = _native.EnvRecord.from_buffer_copy(self._rec)
+            if reward is not None:
+                r.reward, r.terminated = reward[t].data_ptr(), terminated[t].data_ptr()
+            recs.append(r)
+        a_src = actions_out if mode == "random" else actions
+        # the kernels' code objects must be resident before the capture: one eager launch of the same entry on a
+        # scratch copy of the state, then everything it touched is put back
+        keep = (self.state.clone(), int(ctr), self._reward.clone(), self._terminated.clone())
+        a0 = None if a_src is None else a_src[0].clone()
+        r0 = None if reward is None else (reward[0].clone(), terminated[0].clone())
+        obs0 = None if mode != "observe" else {k: v.clone() for k, v in self._obs.items()}
+        self._check(self._launch(self._env_step, ctypes.byref(recs[0]), _ptr(None if a_src is None else a_src[0]),
+                                 _ptr(None if bits is None else bits[0]), 0, code, self._stream()))
+        self._check(self._launch(self._lib.qttt_counter_add, ctr.data_ptr(), 0, self._stream()))
+        self.state.copy_(keep[0]); ctr.fill_(keep[1]); self._reward.copy_(keep[2]); self._terminated.copy_(keep[3])
+        if a0 is not None:
+            a_src[0].copy_(a0)
+        if r0 is not None:
+            reward[0].copy_(r0[0]); terminated[0].copy_(r0[1])
+        if obs0 is not None:
+            for k, v in obs0.items():
+                self._obs[k].copy_(v)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                st = self._stream()
+                for t in range(T):
+                    self._check(self._launch(self._env_step, ctypes.byref(recs[t]), _ptr(None if a_src is None else a_src[t]),
+                                             _ptr(None if bits is None else bits[t]), t, code, st))
+                self._check(self._launch(self._lib.qttt_counter_add, ctr.data_ptr(), T, st))
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return StepGraph(self, graph, T, mode, recs, (actions, bits, actions_out, reward, terminated))
+
+    @staticmethod
+    def _check(rc):
+        if rc:
+            _native.check(rc, "qttt_env_step (graph capture)")
+
     # ------------------------------------------------------------------ checkpointing
     def state_dict(self):
         return {"state": self.state.clone(), "seed": self.seed, "step_idx": self.step_idx,
@@ -515,3 +625,17 @@ class VecEnv:
         self.state.copy_(sd["state"])
         self.seed, self.step_idx = int(sd["seed"]), int(sd["step_idx"])
         self.board_offset, self.auto_reset = int(sd["board_offset"]), bool(sd["auto_reset"])
+
+
+class StepGraph:
+    """A hipGraph of T step launches of one VecEnv (VecEnv.capture).  replay() enqueues all of them with ONE
+    host call on the current stream; reward / terminated / the observation are where capture() was told to
+    put them (or the environment's own buffers, holding the last step's)."""
+
+    def __init__(self, env, graph, n_steps, mode, records, buffers):
+        self.env, self.graph, self.n_steps, self.mode = env, graph, n_steps, mode
+        self._keep = (records, buffers)            # the nodes hold raw pointers into these
+
+    def replay(self):
+        self.graph.replay()
+        return self.env._reward, self.env._terminated

@@ -45,7 +45,7 @@ def test_env_record_call_validates_before_touching_the_device():
     import ctypes
     from qtttgym_amd import _native
     L = _native.lib()
-    assert ctypes.sizeof(_native.EnvRecord) == 104                     # include/qttt.h struct qttt_env, LP64
+    assert ctypes.sizeof(_native.EnvRecord) == 112                     # include/qttt.h struct qttt_env, LP64
     assert L.qttt_env_step(None, None, None, 0, _native.ENV_STEP, None) == -1          # QTTT_ERR_NULL
     rec = _native.EnvRecord(n=0)
     assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, 7, None) == -2            # unknown mode: QTTT_ERR_SIZE

@@ -422,3 +422,73 @@ def test_two_ranks_random_fused_shards_equal_the_single_run_through_returns_gath
         assert total == counters.c.cpu().tolist()                                          # all_reduce == whole-job counters
         assert np.array_equal(shard_turn, turn[lo:hi])                                     # shard == slice of the single run
     assert counters.c[0] > DIST_TOTAL and counters.c[3] == DIST_TOTAL * DIST_T
+
+
+# ---------------------------------------------------------------------------------------------------
+# hipGraph of step launches with the step index on the device (VecEnv.capture, qttt_env.step_counter)
+@pytest.mark.parametrize("n", [4096, 70001])
+def test_captured_random_steps_replay_with_a_fresh_step_index_every_time(n):
+    from qtttgym_amd import VecEnv
+    T, R, seed = 9, 3, 21
+    ob, acts, rew, term = _oracle_random_steps(n, T * R + 2, seed, 0, True)
+    env = VecEnv(n, seed=seed, auto_reset=True)
+    a = torch.zeros((T, n, 2), dtype=torch.uint8, device="cuda")
+    r = torch.zeros((T, n), dtype=torch.float32, device="cuda")
+    tm = torch.zeros((T, n), dtype=torch.bool, device="cuda")
+    g = env.capture(T, "random", actions_out=a, reward=r, terminated=tm)
+    assert env.step_idx == 0 and not bool(a.any())                       # capturing ran nothing
+    for k in range(R):
+        g.replay()
+        torch.cuda.synchronize()
+        sl = slice(k * T, (k + 1) * T)
+        assert np.array_equal(_np(a), acts[sl]), k
+        assert np.array_equal(_np(r).view(np.uint32), rew[sl]), k
+        assert np.array_equal(_np(tm).astype(np.uint8), term[sl]), k
+        assert env.step_idx == (k + 1) * T
+    # eager calls keep working on the same environment (they advance the device counter too)
+    act = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    r1, t1 = env.step_random(actions_out=act)
+    assert np.array_equal(_np(act), acts[T * R]) and np.array_equal(_np(r1).view(np.uint32), rew[T * R])
+    r2, t2 = env.step_raw(env.sample_actions())
+    assert np.array_equal(_np(r2).view(np.uint32), rew[T * R + 1]) and np.array_equal(_np(t2).astype(np.uint8), term[T * R + 1])
+    assert env.step_idx == T * R + 2
+    _assert_same_as_oracle(env, ob)
+    sd = env.state_dict()
+    assert sd["step_idx"] == T * R + 2
+    env.reset()
+    assert env.step_idx == 0
+    g.replay()                                                            # from a fresh reset: the first T steps again
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(a), acts[:T]) and np.array_equal(_np(r).view(np.uint32), rew[:T])
+
+
+def test_captured_step_and_observe_modes_read_the_callers_action_buffer():
+    """The agent-loop shape: a graph of ONE step launch (with the observation) replayed every step, the action
+    buffer refilled in between; collapse bits from the device-side step counter."""
+    from qtttgym_amd import VecEnv
+    n, seed, steps = 5000, 33, 14
+    ob, acts, rew, term = _oracle_random_steps(n, steps, seed, 0, True)
+    env = VecEnv(n, seed=seed, auto_reset=True)
+    a = torch.zeros((1, n, 2), dtype=torch.uint8, device="cuda")
+    g = env.capture(1, "observe", actions=a)
+    ref = oracle.OracleBoards(n)
+    for t in range(steps):
+        a[0].copy_(torch.from_numpy(acts[t]))
+        r, tm = g.replay()
+        ref.step(acts[t], None, seed, t, 0, True)
+        assert np.array_equal(_np(r).view(np.uint32), rew[t]) and np.array_equal(_np(tm).astype(np.uint8), term[t]), t
+        cl = ref.observe()[0]
+        assert np.array_equal(_np(env._obs["classical"]), cl), t
+    _assert_same_as_oracle(env, ob)
+    env2 = VecEnv(n, seed=seed, auto_reset=True)
+    a2 = torch.from_numpy(acts[:6].copy()).cuda()
+    g2 = env2.capture(6, "step", actions=a2)
+    g2.replay()
+    a2.copy_(torch.from_numpy(acts[6:12].copy()))
+    r, tm = g2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(r).view(np.uint32), rew[11]) and env2.step_idx == 12
+    with pytest.raises(ValueError):
+        env2.capture(2, "step")
+    with pytest.raises(ValueError):
+        env2.capture(2, "random", actions=a2[:2])

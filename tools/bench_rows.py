@@ -130,6 +130,23 @@ def main():
                     "us_per_step_reward_terminated_kept": t_rt * 1e6 / T, "us_per_step_last_only": t_last * 1e6 / T,
                     "us_per_step_launch_by_launch": t_one * 1e6, "steps_per_s_all_outputs_kept": n * T / t_keep,
                     "steps_per_s_last_only": n * T / t_last})
+    # launch-per-step on small batches: eager Python loop against a hipGraph of the same launches (VecEnv.capture)
+    for n in (4096, 65536, 262144):
+        T = 32
+        e1 = VecEnv(n, seed=2, auto_reset=True)
+        t_eager = timed(lambda: [e1.step_random() for _ in range(T)], reps=10)
+        e2 = VecEnv(n, seed=2, auto_reset=True)
+        g = e2.capture(T, "random")
+        t_graph = timed(lambda: g.replay(), reps=10)
+        e3 = VecEnv(n, seed=2, auto_reset=True)
+        a = torch.zeros((1, n, 2), dtype=torch.uint8, device="cuda")
+        g1 = e3.capture(1, "observe", actions=a)
+        t_g1 = timed(lambda: g1.replay(), reps=64)
+        e4 = VecEnv(n, seed=2, auto_reset=True)
+        t_e1 = timed(lambda: e4.step_observe_raw(a[0]), reps=64)
+        out.append({"row": "launch_per_step_eager_vs_hipgraph", "boards": n, "steps_per_graph": T,
+                    "step_random_eager_us_per_step": t_eager * 1e6 / T, "step_random_graph_us_per_step": t_graph * 1e6 / T,
+                    "step_observe_eager_us_per_step": t_e1 * 1e6, "step_observe_graph_of_one_us_per_step": t_g1 * 1e6})
     # expand and node_info at a batch that fills the chip, turn() = n_moves alone
     n = 1 << 20
     env = midgame(n, 4)
