@@ -8,6 +8,11 @@ action per board, auto-reset on, episode statistics accumulated on the device.
 The policy here: play the uniform-legal random move, except take the centre square (4) together
 with the first other empty square whenever the centre is still empty — just enough to show a
 policy that depends on `obs["classical"]`.
+
+Aliasing: the loop consumes each observation at once, so it asks for the zero-copy form
+(`copy_obs=False`: the returned tensors are the environment's own buffers and the NEXT step overwrites
+them).  A caller that keeps observations — a replay buffer storing (obs, next_obs) — uses the default
+`env.step(action)`, which returns fresh tensors every call.
 """
 import argparse
 import os
@@ -43,11 +48,11 @@ def main():
     episodes = torch.zeros((), dtype=torch.int64, device=env.device)
     lines = torch.zeros((), dtype=torch.int64, device=env.device)
     for _ in range(10):                                         # warm the allocator and the kernels
-        obs, *_ = env.step(policy(env, obs))
+        obs, *_ = env.step(policy(env, obs), copy_obs=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        obs, reward, terminated, truncated, info = env.step(policy(env, obs))
+        obs, reward, terminated, truncated, info = env.step(policy(env, obs), copy_obs=False)
         episodes += terminated.sum()
         lines += (reward != 0).sum()                           # env.py:49: -1.0 iff somebody holds a line
     torch.cuda.synchronize()
