@@ -298,12 +298,23 @@ __device__ inline void fill_pyhash_lut(u64 *dst) {
 // 32 - 4t.
 struct PyHashWalk {
     u64 acc;
-    u32 W, c8, Qr, kk, sh, n8, last_x;
+    u32 W, c8, Qr, kk, sh, n8, last_x, V, v8;
     bool nine_real, nine;
     __device__ __forceinline__ void init(const Lite &s, u32 P1_stored, u32 Q0) {
         acc = PYH_P5;
         W = (u32)(s.P >> 2);                                        // codes of squares 0..7
         c8 = (u32)(s.P >> 34) & 0xFu;
+        // index of every board element into the table, for eight squares at once: value + 1 = 16 - code where
+        // the square is classical, 0 (the entry of -1) elsewhere.  M = 0xF on the classical squares' nibbles (the
+        // 8 mask bits spread to nibble LSBs, times 15); a classical code is >= 7, so the nibble-wise two's
+        // complement (~code + 1) never carries out of its nibble once the other nibbles are forced to 0xF first.
+        u32 m = s.cl & 0xFFu;
+        m = (m | (m << 12)) & 0x000F000Fu;
+        m = (m | (m << 6)) & 0x03030303u;
+        m = (m | (m << 3)) & 0x11111111u;
+        const u32 M = (m << 4) - m;
+        V = (~(W | ~M) + 0x11111111u) & M;
+        v8 = (s.cl & 0x100u) ? 16u - c8 : 0u;
         last_x = (P1_stored >> P1_LX_SHIFT) & 0xFu;
         nine_real = s.n_real == 9u;
         nine = s.n == 9u;
@@ -313,15 +324,16 @@ struct PyHashWalk {
         sh = 0u;
     }
     __device__ __forceinline__ void board_elem(u32 v, u32 cl, const u64 *tbl) {
-        const u32 c = v < 8u ? (W >> (4u * v)) & 0xFu : c8;
-        acc = pyh_step_dev(acc, tbl[(cl >> v & 1u) ? 16u - c : 0u]);   // board[value + 1], value = 15 - c
+        (void)cl;
+        acc = pyh_step_dev(acc, tbl[v < 8u ? (V >> (4u * v)) & 0xFu : v8]);   // board[value + 1], value = 15 - code
     }
     __device__ __forceinline__ void move_elem(u32 t, const u64 *tbl) {   // t < n8 (an autofill move is always round 8)
         const u32 z = W ^ kk;
         const u32 f = (z - 0x11111111u) & ~z & 0x88888888u;
-        const u32 c = f ? (u32)__builtin_ctz(f) >> 2 : 8u;
-        const u32 o = min(c ^ ((Qr >> sh) & 0xFu), 8u);             // (only a corrupted import could exceed 8)
-        acc = pyh_step_dev(acc, tbl[10u + (c * 9u + o) * 9u + t]);
+        const u32 c = min(ffbl_raw(f) >> 2, 8u);                    // no flag: v_ffbl_b32 gives 0xFFFFFFFF -> square 8
+        const u32 o = c ^ ((Qr >> sh) & 0xFu);                      // <= 8 for any state the kernels produce
+        // entry 10 + (c * 9 + o) * 9 + t as a byte offset: two multiply-adds, no shift
+        acc = pyh_step_dev(acc, *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(tbl) + (80u + 8u * t) + c * 648u + o * 72u));
         kk -= 0x11111111u;
         sh = (sh - 4u) & 31u;
     }

@@ -468,8 +468,16 @@ int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_
     if (!state) return QTTT_ERR_NULL;
     if (!winner && !terminal && !legal && !key) return 0;                   // nothing asked for
     Planes p = planes(const_cast<void *>(state), n);
-    hipLaunchKernelGGL(node_info_kernel, dim3(grid_for((n + 1) / 2)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
-                       p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
+    // workgroup size by batch (tools/rowbench, us per launch, 256 / 512 / 1024 threads: 1 M boards 11.7 / 11.2 / 10.5 —
+    // the 12 KB of tables are filled once per workgroup; 64 K boards 4.6 / 4.7 / 5.8 — latency-bound).  Measured and not
+    // adopted: a 1 000-entry table of the accumulator after the first three board elements (three multiply steps
+    // less per board): 10.2 us with 1024 threads, but every smaller shape and expand lose as much to the 8 KB fill.
+    if (n >= 384 * 1024)
+        hipLaunchKernelGGL((node_info_kernel<1024>), dim3(blocks_for((n + 1) / 2, 1024)), dim3(1024), 0, (hipStream_t)stream,
+                           p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
+    else
+        hipLaunchKernelGGL((node_info_kernel<256>), dim3(blocks_for((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream,
+                           p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
     return launch_status();
 }
 
@@ -484,9 +492,14 @@ int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *
     if (((uintptr_t)winner & 1u) || ((uintptr_t)terminal & 1u) || ((uintptr_t)legal & 15u) || ((uintptr_t)key & 15u))
         return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
-    hipLaunchKernelGGL(expand_kernel, dim3(grid_for(n)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
-                       p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner,
-                       terminal, (u64 *)legal, key, n);
+    // workgroup size by batch, as node_info (tools/rowbench, 256 / 512 / 1024 threads: 1 M pairs 27.4 / 26.6 / 25.9 us,
+    // 64 K pairs 5.6 / 6.0 / 7.9)
+    if (n >= 384 * 1024)
+        hipLaunchKernelGGL((expand_kernel<1024>), dim3(blocks_for(n, 1024)), dim3(1024), 0, (hipStream_t)stream,
+                           p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner, terminal, (u64 *)legal, key, n);
+    else
+        hipLaunchKernelGGL((expand_kernel<256>), dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner, terminal, (u64 *)legal, key, n);
     return launch_status();
 }
 

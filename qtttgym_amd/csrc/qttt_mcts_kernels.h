@@ -22,13 +22,14 @@ __constant__ PairLut g_pair_lut = PairLut();
 // Two boards per lane (one 16-byte load per plane, 16-byte stores of the two legal masks and the two
 // keys): the CPython tuple hash is a dependent chain per board, two chains in one lane interleave
 // (fast_py_hash_pair).  The last board of an odd batch is handled alone.
-__global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
     int64_t *key, int64_t n) {
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
     __shared__ u64 ltbl[512];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    const int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;   // boards 2j, 2j + 1
+    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;   // boards 2j, 2j + 1
     const int64_t i0 = 2 * j;
     typedef Vec<u64, 2> V64;
     V64 p, q;
@@ -40,9 +41,9 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
         p.v[0] = pP[i0];
         if (key) q.v[0] = pQ[i0];
     }
-    if (key) fill_pyhash_lut<QTTT_BLOCK>(htbl);
-    if (legal) fill_legal_lut<QTTT_BLOCK>(ltbl);
-    fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
+    if (key) fill_pyhash_lut<BLOCK>(htbl);
+    if (legal) fill_legal_lut<BLOCK>(ltbl);
+    fill_line_lut<BLOCK>(lut);                       // ends with the workgroup barrier
     if (i0 >= n) return;
     const Lite sa = lite_unpack(p.v[0]), sb = lite_unpack(p.v[1]);
     const bool two = i0 + 1 < n;
@@ -89,19 +90,20 @@ __global__ __launch_bounds__(QTTT_BLOCK) void node_info_kernel(
 // mask, key) is computed as a pair — two independent hash chains in one lane, as in node_info — and
 // masked by n_children afterwards (child 1 is a valid state even when there is no collapse: it equals
 // child 0).
-__global__ __launch_bounds__(QTTT_BLOCK) void expand_kernel(
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void expand_kernel(
     const u64 *pP, const u64 *pQ, const uint8_t *action36,
     u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, uint8_t *n_children,
     int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ u64 htbl[PYHASH_LUT_WORDS];
     __shared__ u64 ltbl[512];
-    int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;  // requested before the table fills
     const u32 a = i < n ? (u32)action36[i] : 0u;
-    fill_pyhash_lut<QTTT_BLOCK>(htbl);
-    fill_legal_lut<QTTT_BLOCK>(ltbl);
-    fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
+    fill_pyhash_lut<BLOCK>(htbl);
+    fill_legal_lut<BLOCK>(ltbl);
+    fill_line_lut<BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
     const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);

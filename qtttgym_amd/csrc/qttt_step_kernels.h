@@ -202,7 +202,8 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
     __shared__ uint8_t nth9[512 * 9];
-    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t ib = (int64_t)blockIdx.x * BLOCK;                 // first board of the workgroup (block-uniform)
+    const int64_t i = ib + threadIdx.x;
     const bool active = i < n;
     const int64_t il = active ? i : 0;                              // idle lanes re-read board 0, store nothing
     const u64 P = load_stream(&pP[il]), Q = load_stream(&pQ[il]);   // requested before the table fills
@@ -212,6 +213,12 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     if (!active) return;
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
     const u32 id = fold_id(board_offset + (u64)i);
+    // per-ply outputs: a block-uniform 64-bit base (scalar unit, advanced by the stride every ply) plus the
+    // lane's 32-bit offset — no 64-bit vector address arithmetic in the loop
+    uint16_t *a_blk = actions_out ? actions_out + ib : nullptr;
+    u32 *r_blk = reward_bits ? reward_bits + ib : nullptr;
+    uint8_t *t_blk = terminated ? terminated + ib : nullptr;
+    const u32 lane = threadIdx.x;
     for (int32_t t = 0; t < n_steps; ++t) {
         const u64 key = launch_key(seed, step_idx0 + (u32)t);       // wave-uniform: scalar unit
         const u32 h1 = lowbias32(id ^ (u32)key);
@@ -230,13 +237,14 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
             win = step_core<false, false>(P0, P1, Q0, Q1, act, h1 >> 31, lut);
         }
         if (out_stride != 0 || t == n_steps - 1) {
-            const int64_t o = (int64_t)t * out_stride + i;
-            if (actions_out) store_stream(&actions_out[o], (uint16_t)act);
-            if (reward_bits) {
-                store_stream(&reward_bits[o], 0x80000000u | (win << 23));     // env.py:49: -1.0f / -0.0f
-                store_stream(&terminated[o], (uint8_t)(P1 >> 31));            // env.py:51
+            if (a_blk) store_stream(&a_blk[lane], (uint16_t)act);
+            if (r_blk) {
+                store_stream(&r_blk[lane], 0x80000000u | (win << 23));        // env.py:49: -1.0f / -0.0f
+                store_stream(&t_blk[lane], (uint8_t)(P1 >> 31));              // env.py:51
             }
         }
+        if (a_blk) a_blk += out_stride;
+        if (r_blk) { r_blk += out_stride; t_blk += out_stride; }
     }
     store_stream(&pP[i], (u64)P0 | ((u64)P1 << 32));
     store_stream(&pQ[i], (u64)Q0 | ((u64)Q1 << 32));

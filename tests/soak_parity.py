@@ -36,10 +36,24 @@ def one_case(rng, k):
     observe = bool(rng.integers(0, 2))
     seed = int(rng.integers(0, 2**62))
     steps = int(rng.integers(3, 14)) if n < 600000 else int(rng.integers(3, 7))
-    assert L.qttt_set_tuning(*shape) == 0
-    env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    per_call = bool(rng.integers(0, 2))               # the launch shape in the calls' own flags, or the process default
+    assert L.qttt_set_tuning(*((0, 0) if per_call else shape)) == 0
+    env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off,
+                 launch_shape=shape if per_call and shape != (0, 0) else None)
     ob = oracle.OracleBoards(n)
-    for t in range(steps):
+    fused = int(rng.integers(0, 6)) if (not adversarial and not use_bits) else 0   # a run of fused random plies first
+    if fused:
+        acts = torch.empty((fused, n, 2), dtype=torch.uint8, device=env.device)
+        rr = torch.empty((fused, n), dtype=torch.float32, device=env.device)
+        tt = torch.empty((fused, n), dtype=torch.bool, device=env.device)
+        env.step_random_many(fused, actions_out=acts, reward=rr, terminated=tt)
+        for t in range(fused):
+            a_or = ob.sample_actions(seed, t, off, auto_reset)
+            r_or, t_or = ob.step(a_or, None, seed, t, off, auto_reset)
+            assert np.array_equal(npy(acts[t]), a_or), ("fused policy", t)
+            assert np.array_equal(npy(rr[t]).view(np.uint32), r_or.view(np.uint32)), ("fused reward", t)
+            assert np.array_equal(npy(tt[t]).astype(np.uint8), t_or), ("fused terminated", t)
+    for t in range(fused, fused + steps):
         a_or = ob.sample_actions(seed, t, off, auto_reset)
         a = env.sample_actions()
         assert np.array_equal(npy(a), a_or), ("policy", t)
@@ -66,11 +80,12 @@ def one_case(rng, k):
     ex = {kk: npy(v) for kk, v in env.export_boards().items()}
     assert np.array_equal(ex["board"], ob.board) and np.array_equal(ex["moves"], ob.moves)
     assert np.array_equal(ex["n_moves"], ob.n_moves) and np.array_equal(ex["qmask"].view(np.uint16), ob.qmask)
+    assert np.array_equal(ex["n_q"], ob.n_q) and np.array_equal(npy(env.turn()), ob.n_moves)
     p1, p2 = env.check_win()
     w1, w2 = ob.check_win()
     assert np.array_equal(npy(p1), w1) and np.array_equal(npy(p2), w2)
-    return dict(case=k, n=n, offset=off, shape=shape, auto_reset=auto_reset, bits=use_bits, adversarial=adversarial,
-                observe=observe, steps=steps)
+    return dict(case=k, n=n, offset=off, shape=shape, per_call=per_call, auto_reset=auto_reset, bits=use_bits,
+                adversarial=adversarial, observe=observe, fused_plies=fused, steps=steps)
 
 
 def rows_case(rng, k):

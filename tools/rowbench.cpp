@@ -80,12 +80,23 @@ int main(int argc, char **argv) {
     vs.push_back({"export_floor<" #BLK "," #BPL ">", [=](hipStream_t st) {                                               \
         hipLaunchKernelGGL((export_floor<BLK, BPL>), dim3((unsigned)((n + BLK * BPL - 1) / (BLK * BPL))), dim3(BLK), 0, st, p.P, p.Q, eo, n); }, {}});
     EXPV(256, 1) EXPV(512, 1) EXPV(1024, 1) EXPV(256, 2) EXPV(512, 2) EXPV(1024, 2)
-    vs.push_back({"node_info (2 boards per lane, 512)", [=](hipStream_t st) {
-        hipLaunchKernelGGL(node_info_kernel, dim3((unsigned)(((n + 1) / 2 + QTTT_BLOCK - 1) / QTTT_BLOCK)), dim3(QTTT_BLOCK), 0, st,
-                           p.P, p.Q, winner, terminal, legal, key, n); }, {}});
-    vs.push_back({"node_info without key", [=](hipStream_t st) {
-        hipLaunchKernelGGL(node_info_kernel, dim3((unsigned)(((n + 1) / 2 + QTTT_BLOCK - 1) / QTTT_BLOCK)), dim3(QTTT_BLOCK), 0, st,
+#define NIV(BLK)                                                                                                         \
+    vs.push_back({"node_info<" #BLK ">", [=](hipStream_t st) {                                                           \
+        hipLaunchKernelGGL((node_info_kernel<BLK>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,   \
+                           p.P, p.Q, winner, terminal, legal, key, n); }, {}});                                         \
+    vs.push_back({"node_info<" #BLK "> without key", [=](hipStream_t st) {                                               \
+        hipLaunchKernelGGL((node_info_kernel<BLK>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,   \
                            p.P, p.Q, winner, terminal, legal, (int64_t *)nullptr, n); }, {}});
+    NIV(256) NIV(512) NIV(1024)
+    uint8_t *act36, *nch; u64 *kid0, *kid1; int8_t *w2; uint8_t *t2; u64 *l2; int64_t *k2;
+    CK(hipMalloc(&act36, n)); CK(hipMemset(act36, 7, n)); CK(hipMalloc(&nch, n)); CK(hipMalloc(&kid0, s64 * 16)); CK(hipMalloc(&kid1, s64 * 16));
+    CK(hipMalloc(&w2, 2 * n)); CK(hipMalloc(&t2, 2 * n)); CK(hipMalloc(&l2, 16 * n)); CK(hipMalloc(&k2, 16 * n));
+    Planes c0 = planes(kid0, n), c1 = planes(kid1, n);
+#define EXV(BLK)                                                                                                         \
+    vs.push_back({"expand<" #BLK "> (action 7 everywhere)", [=](hipStream_t st) {                                        \
+        hipLaunchKernelGGL((expand_kernel<BLK>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, st, p.P, p.Q, act36, \
+                           c0.P, c0.Q, c1.P, c1.Q, nch, w2, t2, l2, k2, n); }, {}});
+    EXV(256) EXV(512) EXV(1024)
     ObsOut oo;
     CK(hipMalloc(&oo.classical, n * 9)); CK(hipMalloc(&oo.q_p1, n * 10)); CK(hipMalloc(&oo.q_p1_len, n));
     CK(hipMalloc(&oo.q_p2, n * 8)); CK(hipMalloc(&oo.q_p2_len, n)); CK(hipMalloc(&oo.turn, n));
