@@ -17,8 +17,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qtttgym_amd import VecEnv  # noqa: E402
-
-PAIRS = torch.tensor([(i, j) for i in range(9) for j in range(i + 1, 9)], dtype=torch.uint8)  # ind2move
+from qtttgym_amd.actions import action36_to_pairs  # noqa: E402  (ind2move for a whole batch, mcts.py:339-343)
 
 
 def search_actions(env, sims, sweep):
@@ -34,9 +33,10 @@ def search_actions(env, sims, sweep):
     value = torch.zeros(G * 36, device=dev)
     for c, child in enumerate((out["child0"], out["child1"])):
         tot = torch.zeros(G * 36, device=dev)
+        ro = None
         for s in range(sims):
-            r, _ = child.rollout(step_idx0=100 + 16 * (sweep * sims + s))
-            tot += r.to(torch.float32)
+            ro = child.rollout(step_idx0=100 + 16 * (sweep * sims + s), out=ro)   # the same two buffers every playout
+            tot += ro[0].to(torch.float32)
         value += torch.where(nch > c, tot / sims, torch.zeros_like(tot))
     value = value / nch.clamp(min=1)                                # both collapse branches equally likely
     value = torch.where(nch > 0, value, torch.full_like(value, -2.0))
@@ -51,12 +51,11 @@ def main():
     args = ap.parse_args()
     G = args.games
     env = VecEnv(G, seed=args.seed)
-    pairs = PAIRS.to(env.device)
     finished = torch.zeros(G, dtype=torch.bool, device=env.device)
     for ply in range(9):
         if ply % 2 == 0:
             a36 = search_actions(env, args.sims, ply)
-            actions = pairs[a36.long()]
+            actions = action36_to_pairs(a36)
         else:
             actions = env.sample_actions()
         actions = torch.where(finished[:, None], torch.full_like(actions, 255), actions)   # freeze finished games

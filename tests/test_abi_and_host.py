@@ -196,3 +196,25 @@ def test_bench_self_launch_propagates_a_failing_rank():
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "no HIP device visible" in out.stderr or "needs 2 GPUs" in out.stderr
+
+
+def test_action_indexing_matches_the_reference_formulas():
+    """mcts.py:339-350: ind2move(n) = (i, j) by the closed form, move2ind its inverse (either order); the
+    package's table-based versions and the batched tensor forms agree with them (host logic, CPU)."""
+    import math
+    import torch
+    from qtttgym_amd import ind2move, move2ind
+    from qtttgym_amd.actions import action36_to_pairs, pairs_to_action36, legal_mask_to_bool
+    for n in range(36):
+        i = int((17 - math.sqrt(17 * 17 - 8 * n)) / 2)                 # the reference's arithmetic, restated
+        j = (2 * n + 2 - 15 * i + i * i) // 2
+        assert ind2move(n) == (i, j) and 0 <= i < j <= 8
+        assert move2ind(i, j) == n == move2ind(j, i) == (15 * i - i * i + 2 * j - 2) // 2
+    assert [ind2move(n) for n in (0, 7, 8, 35)] == [(0, 1), (0, 8), (1, 2), (7, 8)]   # SURVEY Appendix A
+    a = torch.tensor([0, 7, 8, 35, 36, 255], dtype=torch.uint8)
+    p = action36_to_pairs(a)
+    assert p.tolist() == [[0, 1], [0, 8], [1, 2], [7, 8], [255, 255], [255, 255]]
+    back = pairs_to_action36(torch.tensor([[1, 0], [8, 0], [2, 1], [7, 8], [4, 4], [9, 1]], dtype=torch.uint8))
+    assert back.tolist() == [0, 7, 8, 35, 255, 255]
+    m = legal_mask_to_bool(torch.tensor([0, 1 | (1 << 35), (1 << 36) - 1], dtype=torch.int64))
+    assert m.shape == (3, 36) and m[0].sum() == 0 and m[1].nonzero().flatten().tolist() == [0, 35] and bool(m[2].all())

@@ -41,13 +41,13 @@ def _oracle_random_steps(n, T, seed, off, auto_reset, step_idx0=0):
     return ob, acts, rew, term
 
 
-@pytest.mark.parametrize("n,T", [(1, 1), (1, 9), (1, 64), (4096, 1), (4096, 9), (4096, 64), (262144, 9),
-                                 (262144, 64), (1048577, 9)])
+@pytest.mark.parametrize("n,T", [(1, 1), (1, 9), (1, 64), (4096, 1), (4096, 9), (4096, 64), (262144, 1), (262144, 9),
+                                 (262144, 64), (1048577, 1), (1048577, 9), (1048577, 64)])
 @pytest.mark.parametrize("auto_reset", [False, True])
 def test_step_random_many_every_output_kept_vs_oracle(n, T, auto_reset):
     from qtttgym_amd import VecEnv
-    if n == 262144 and T == 64 and not auto_reset:
-        pytest.skip("covered by the auto-reset case; keeps the suite short")
+    if n >= 262144 and T == 64 and not auto_reset:
+        pytest.skip("64 plies without auto-reset are 55 noops on finished boards: covered at 4 096 boards; keeps the suite short")
     seed, off = 4242 + n + T, 3 * n
     ob, acts, rew, term = _oracle_random_steps(n, T, seed, off, auto_reset)
     env = VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
