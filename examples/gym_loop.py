@@ -3,7 +3,11 @@
 for N boards at once: a policy that reads the observation tensors on the GPU and answers with an
 action per board, auto-reset on, episode statistics accumulated on the device.
 
-    python examples/gym_loop.py [--boards 262144] [--steps 200]
+    python examples/gym_loop.py [--boards 262144] [--steps 200] [--graph]
+
+--graph: one whole agent step (policy reading the observation, env.step, the statistics) is captured in a hipGraph
+and replayed: possible because the step index lives on the device (VecEnv.use_device_step_counter), so every
+replay draws fresh collapse bits, and because no call of the library allocates, synchronises or queries.
 
 The policy here: play the uniform-legal random move, except take the centre square (4) together
 with the first other empty square whenever the centre is still empty — just enough to show a
@@ -42,19 +46,40 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--boards", type=int, default=262144)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     env = VecEnv(args.boards, seed=1, auto_reset=True)
     obs, _ = env.reset()
     episodes = torch.zeros((), dtype=torch.int64, device=env.device)
     lines = torch.zeros((), dtype=torch.int64, device=env.device)
-    for _ in range(10):                                         # warm the allocator and the kernels
-        obs, *_ = env.step(policy(env, obs), copy_obs=False)
+
+    def agent_step():
+        # obs are the environment's own buffers: the step overwrites them in place (copy_obs=False)
+        _, reward, terminated, truncated, info = env.step(policy(env, obs), copy_obs=False)
+        episodes.add_(terminated.sum())
+        lines.add_((reward != 0).sum())                        # env.py:49: -1.0 iff somebody holds a line
+
+    if args.graph:
+        env.use_device_step_counter()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(10):                                 # warm the allocator and the kernels
+                agent_step()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                agent_step()
+        torch.cuda.current_stream().wait_stream(side)
+        run = g.replay
+    else:
+        for _ in range(10):
+            agent_step()
+        run = agent_step
+    episodes.zero_(); lines.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        obs, reward, terminated, truncated, info = env.step(policy(env, obs), copy_obs=False)
-        episodes += terminated.sum()
-        lines += (reward != 0).sum()                           # env.py:49: -1.0 iff somebody holds a line
+        run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("%d boards x %d steps in %.3f s = %.3g env steps/s (policy included); %d episodes finished, %d with a line"

@@ -213,6 +213,7 @@ typedef struct qttt_env {
 #define QTTT_ENV_STEP         0     /* = qttt_step(actions, bits) */
 #define QTTT_ENV_STEP_OBSERVE 1     /* = qttt_step_observe(actions, bits) */
 #define QTTT_ENV_STEP_RANDOM  2     /* = qttt_step_random(actions_out = actions, nullable); bits ignored */
+#define QTTT_ENV_SAMPLE       3     /* = qttt_sample_actions(actions): the policy alone, the state is not touched */
 int qttt_env_step(const qttt_env *env, uint8_t *actions, const uint8_t *bits, uint32_t step_idx,
                   int mode, void *stream);
 /* *counter += by, on the stream (one lane): advances a qttt_env.step_counter; capturable like every other entry */

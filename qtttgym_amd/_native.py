@@ -22,7 +22,7 @@ class EnvRecord(ctypes.Structure):
                 ("q_p2_len", ctypes.c_void_p), ("turn", ctypes.c_void_p), ("step_counter", ctypes.c_void_p)]
 
 
-ENV_STEP, ENV_STEP_OBSERVE, ENV_STEP_RANDOM = 0, 1, 2
+ENV_STEP, ENV_STEP_OBSERVE, ENV_STEP_RANDOM, ENV_SAMPLE = 0, 1, 2, 3
 
 # every symbol include/qttt.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64,

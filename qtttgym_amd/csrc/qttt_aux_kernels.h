@@ -385,10 +385,17 @@ __device__ __forceinline__ u32 sampled_action(const uint8_t *plut, u64 Pw, u64 b
     return (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
 }
 
+// step_ctr (nullable): the step index is key_hi + *step_ctr and the launch key is made here (qttt_env.step_counter,
+// see step_kernel's DEVSTEP); then key_lo is unused and `seed` is the environment's seed
 __global__ __launch_bounds__(QTTT_BLOCK) void sample_actions_kernel(
     const u64 *pP, u32 key_lo, u32 key_hi, u64 board_offset, u32 auto_reset, uint16_t *actions,
-    int64_t n) {
+    int64_t n, const u32 *step_ctr, u64 seed) {
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    if (step_ctr) {
+        const u64 key = launch_key(seed, key_hi + *step_ctr);
+        key_lo = (u32)key;
+        key_hi = (u32)(key >> 32);
+    }
     const int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;   // boards 2j, 2j+1
     const int64_t i0 = 2 * j;
     typedef Vec<u64, 2> V64;

@@ -282,6 +282,9 @@ int qttt_step_random(void *state, uint64_t seed, uint32_t step_idx, int64_t boar
                        terminated, n, stream, true, nullptr);
 }
 
+static int launch_sample(const void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                         uint32_t flags, uint8_t *actions, int64_t n, void *stream, const uint32_t *step_ctr);
+
 int qttt_env_step(const qttt_env *e, uint8_t *actions, const uint8_t *bits, uint32_t step_idx, int mode,
                   void *stream) {
     if (!e) return QTTT_ERR_NULL;
@@ -299,6 +302,8 @@ int qttt_env_step(const qttt_env *e, uint8_t *actions, const uint8_t *bits, uint
     case QTTT_ENV_STEP_RANDOM:
         return launch_step(e->state, actions, nullptr, e->seed, step_idx, e->board_offset, e->flags, e->reward,
                            e->terminated, e->n, stream, true, nullptr, e->step_counter);
+    case QTTT_ENV_SAMPLE:
+        return launch_sample(e->state, e->seed, step_idx, e->board_offset, e->flags, actions, e->n, stream, e->step_counter);
     default:
         return QTTT_ERR_SIZE;
     }
@@ -447,18 +452,24 @@ int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, voi
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
-                        uint32_t flags, uint8_t *actions, int64_t n, void *stream) {
+static int launch_sample(const void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                         uint32_t flags, uint8_t *actions, int64_t n, void *stream, const uint32_t *step_ctr) {
     if (n < 0 || board_offset < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state || !actions) return QTTT_ERR_NULL;
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // written as u16 pairs
     Planes p = planes(const_cast<void *>(state), n);
-    const u64 key = launch_key(seed, step_idx);
+    const u64 key = step_ctr ? ((u64)step_idx << 32) : launch_key(seed, step_idx);
     hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for((n + 1) / 2)), dim3(QTTT_BLOCK), 0,
                        (hipStream_t)stream, p.P, (u32)key, (u32)(key >> 32), (u64)board_offset,
-                       (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), reinterpret_cast<uint16_t *>(actions), n);
+                       (u32)((flags & QTTT_FLAG_AUTO_RESET) != 0), reinterpret_cast<uint16_t *>(actions), n,
+                       step_ctr, (u64)seed);
     return launch_status();
+}
+
+int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int64_t board_offset,
+                        uint32_t flags, uint8_t *actions, int64_t n, void *stream) {
+    return launch_sample(state, seed, step_idx, board_offset, flags, actions, n, stream, nullptr);
 }
 
 int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,

@@ -381,8 +381,9 @@ class VecEnv:
                 out = torch.empty((n, 2), dtype=torch.uint8, device=self.device)
         elif out.dtype != torch.uint8 or out.numel() != 2 * n or not out.is_contiguous() or out.device != self.state.device:
             raise ValueError("out must be a contiguous uint8 device tensor of shape (N, 2)")
-        rc = self._launch(self._lib.qttt_sample_actions, self.state.data_ptr(), self.seed, self.step_idx,
-                          self.board_offset, self._flags(), out.data_ptr(), n, self._stream())
+        # through the qttt_env record: with a device-side step counter the call stays capturable in a hipGraph
+        rc = self._launch(self._env_step, self._record(), out.data_ptr(), None, self._step_host, _native.ENV_SAMPLE,
+                          self._stream())
         _native.check(rc, "qttt_sample_actions")
         return out
 

@@ -492,3 +492,41 @@ def test_captured_step_and_observe_modes_read_the_callers_action_buffer():
         env2.capture(2, "step")
     with pytest.raises(ValueError):
         env2.capture(2, "random", actions=a2[:2])
+
+
+def test_a_whole_agent_step_is_graph_capturable_with_the_device_step_counter():
+    """The caller's own graph (not VecEnv.capture): policy kernel + torch ops + step with observation captured
+    once, replayed; equals the eager loop of another environment (and so, transitively, the oracle)."""
+    from qtttgym_amd import VecEnv
+    n, seed, steps = 3000, 44, 12
+    ref = VecEnv(n, seed=seed, auto_reset=True)
+    env = VecEnv(n, seed=seed, auto_reset=True)
+    env.use_device_step_counter()
+    env.observ()
+    total = torch.zeros((), dtype=torch.int64, device="cuda")
+
+    def agent_step(e, acc):
+        a = e.sample_actions()
+        a = torch.where(e._obs["turn"][:, None] > 1, torch.zeros_like(a), a)      # (a policy that reads the observation)
+        _, r, tm = e.step_observe_raw(a)
+        acc.add_(tm.sum())
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        warm = VecEnv(n, seed=seed, auto_reset=True)
+        warm.use_device_step_counter(); warm.observ()
+        agent_step(warm, torch.zeros_like(total))                                  # kernels resident before the capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            agent_step(env, total)
+    torch.cuda.current_stream().wait_stream(side)
+    want = torch.zeros_like(total)
+    ref.observ()
+    for t in range(steps):
+        g.replay()
+        agent_step(ref, want)
+        torch.cuda.synchronize()
+        assert torch.equal(env.state, ref.state), t
+        assert torch.equal(env._obs["classical"], ref._obs["classical"]), t
+    assert int(total) == int(want) > 0 and env.step_idx == steps == ref.step_idx
