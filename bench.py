@@ -388,9 +388,9 @@ def run_legs(torch, dev, args):
     return legs
 
 
-# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 155 547 054 per dispatch of 1 048 576 boards x
-# 64 steps = 9 493.8 per wave = 148.3 per ply (profiles/r03/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass)
-FUSED_VALU_PER_STEP = 148.3
+# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 154 449 327 per dispatch of 1 048 576 boards x
+# 64 steps = 9 426.8 per wave = 147.3 per ply (profiles/r03/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass)
+FUSED_VALU_PER_STEP = 147.3
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):
