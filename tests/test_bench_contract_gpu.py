@@ -176,3 +176,21 @@ def test_bench_under_torchrun_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["self_launched"] is False
     assert "cpu_baseline" not in d                                      # rank 0 at N = 1 only
+
+
+def test_bench_two_ranks_on_rccl_when_two_gpus_are_visible():
+    """The real N > 1 path — one rank per GPU, process group on RCCL, device barrier, device all_reduces and the
+    returns gather over xGMI.  Needs two GPUs: skipped on the one-GPU boxes this suite normally runs on (DESIGN.md §8
+    lists these calls as never executed with world > 1 until a node runs this test or the driver's SCALE bench)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    d = run_bench("--gpus", "2", "--boards", "262144", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 == d["ranks_seen"] and d["config"]["dist_backend"] == "nccl"
+    assert d["config"]["replay_matches_recording"] is True and d["scaling"] == "weak"
+    assert d["returns_gather"]["backend"] == "nccl" and d["returns_gather"]["boards_gathered"] == 2 * 262144
+    s = run_bench("--gpus", "2", "--total-boards", "524288", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                  "--mode", "random-fused")
+    assert s["scaling"] == "strong" and s["config"]["boards_per_gpu"] == 262144 and s["ranks_seen"] == 2
+    one = run_bench("--boards", "524288", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs")
+    assert one["config"]["episodes_finished"] == d["config"]["episodes_finished"]      # the same 524 288 boards, sharded or not
