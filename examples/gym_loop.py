@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     env = VecEnv(args.boards, seed=1, auto_reset=True)
-    obs, _ = env.reset()
+    obs, _ = env.reset(copy_obs=False)                          # the environment's own buffers: every step refreshes them
     episodes = torch.zeros((), dtype=torch.int64, device=env.device)
     lines = torch.zeros((), dtype=torch.int64, device=env.device)
 

@@ -156,11 +156,14 @@ class VecEnv:
             _native.check(self._lib.qttt_reset(self.state.data_ptr(), self.num_envs, self._stream()),
                           "qttt_reset")
 
-    def reset(self, *, seed=None, options=None):
+    def reset(self, *, seed=None, options=None, copy_obs=True):
         """env.py:55-57: fresh boards; `seed`/`options` accepted and ignored like the reference,
-        except that an int `seed` re-keys the collapse-bit hash (the reference has no per-env RNG)."""
+        except that an int `seed` re-keys the collapse-bit hash (the reference has no per-env RNG).
+        The observation is a fresh copy unless copy_obs=False (then: the environment's own buffers, which the
+        next step()/observ() overwrites — as for step())."""
         self.reset_raw(seed)
-        return self.observ(), {}
+        obs = self.observ()
+        return ({k: v.clone() for k, v in obs.items()} if copy_obs else obs), {}
 
     def step_raw(self, actions, bits=None):
         """The hot path alone: one fused kernel launch, no observation unpack.

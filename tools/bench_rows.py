@@ -108,7 +108,7 @@ def main():
         tm = torch.empty((T, n), dtype=torch.bool, device="cuda")
 
         def run(fused):
-            env.reset()
+            env.reset_raw()
             env.step_many(actions, reward=r, terminated=tm, fused=fused)
         tf = timed(lambda: run(True), reps=10)
         tu = timed(lambda: run(False), reps=10)
