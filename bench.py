@@ -369,7 +369,9 @@ def run_legs(torch, dev, args):
                        valu_insts_per_board_step=FUSED_VALU_PER_STEP, valu_source="profiles/r03/pmc_sq_fused_summary.csv",
                        valu_peak_ginst_per_s=VALU_PEAK_GINST,
                        valu_frac=None if FUSED_VALU_PER_STEP is None else
-                       FUSED_VALU_PER_STEP * (B / 64.0) / (ev / K * 1e9) / VALU_PEAK_GINST)
+                       FUSED_VALU_PER_STEP * (B / 64.0) / (ev / K * 1e9) / VALU_PEAK_GINST,
+                       issue_ns_per_wave_ply=FUSED_ISSUE_NS_PER_WAVE_PLY, issue_source="tools/isa_mix.py",
+                       issue_frac=FUSED_ISSUE_NS_PER_WAVE_PLY * (B / 64.0 / 1024.0) / (ev / K * 1e9))
         else:
             leg["us_per_launch"] = us
         legs.append(leg)
@@ -391,6 +393,9 @@ def run_legs(torch, dev, args):
 # SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 154 449 327 per dispatch of 1 048 576 boards x
 # 64 steps = 9 426.8 per wave = 147.3 per ply (profiles/r03/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass)
 FUSED_VALU_PER_STEP = 147.3
+# issue time of that instruction mix per wave and ply (tools/isa_mix.py: 65 % of the 147.3 in the slow class, 1.75 ns
+# per instruction per SIMD, the rest at 1.03 ns): what a SIMD needs per resident wave and ply when it never idles
+FUSED_ISSUE_NS_PER_WAVE_PLY = 220.8
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):
