@@ -297,3 +297,40 @@ def test_encode_at_one_million_boards_against_a_torch_restatement():
     wv, wm = to_vector_torch(env.export_boards())
     assert torch.equal(mask, wm)
     assert torch.equal(vec, wv)
+
+
+def test_rollout_at_one_million_boards_equals_ply_by_ply_play():
+    """MCTS._simulate (mcts.py:185-198): the fused playout's (result, plies, final state) against the same policy
+    played one launch per ply on a copy, where every board is looked at the moment it first terminates."""
+    from qtttgym_amd import VecEnv
+    n, s0 = 1 << 20, 40
+    env = VecEnv(n, seed=9)
+    depth = (torch.arange(n, device="cuda") * 2654435761 % 7).to(torch.uint8)                  # parents at depths 0..6
+    a = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(6):
+        env.sample_actions(out=a)
+        a[depth <= t] = 0
+        env.step_raw(a)
+    result, plies, final = env.rollout(step_idx0=s0, return_final=True)
+    cp = VecEnv.from_state(env.state.clone(), n, seed=9)
+    cp.step_idx = s0
+    info = cp.node_info()
+    done = info["terminal"].clone()                                                             # terminal parents: zero plies
+    want_res = torch.where(info["winner"] < 0, torch.zeros_like(info["winner"]), info["winner"] * 2 - 1)
+    want_plies = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    planes = lambda st: st.view(torch.int64).view(2, -1)[:, :n]
+    want_final = planes(cp.state).clone()
+    for p in range(9):
+        cp.step_random()                                                                        # finished boards play on (or noop): ignored below
+        info = cp.node_info(out=info)
+        newly = info["terminal"] & ~done
+        alive = ~done
+        want_plies = torch.where(alive, torch.full_like(want_plies, p + 1), want_plies)
+        res = torch.where(info["winner"] < 0, torch.zeros_like(info["winner"]), info["winner"] * 2 - 1)   # mcts.py:200-209
+        want_res = torch.where(alive, res, want_res)
+        want_final = torch.where(alive[None, :], planes(cp.state), want_final)
+        done |= newly
+    assert bool(done.all())
+    assert torch.equal(plies, want_plies) and torch.equal(result, want_res)
+    assert torch.equal(planes(final.state), want_final)
+    assert int((plies == 0).sum()) > 0 and int(plies.max()) == 9 and int((result == 0).sum()) > n // 20
