@@ -530,3 +530,36 @@ def test_a_whole_agent_step_is_graph_capturable_with_the_device_step_counter():
         assert torch.equal(env.state, ref.state), t
         assert torch.equal(env._obs["classical"], ref._obs["classical"]), t
     assert int(total) == int(want) > 0 and env.step_idx == steps == ref.step_idx
+
+
+def test_checkpoint_round_trip_with_the_device_step_counter_and_python_inputs():
+    """state_dict / load_state_dict carry the step index whether it lives on the host or on the device; step() takes
+    Python lists / numpy arrays / wide integer tensors (out-of-range values are noops, env.py:41)."""
+    from qtttgym_amd import VecEnv
+    n, seed = 2000, 3
+    a = VecEnv(n, seed=seed, auto_reset=True)
+    a.step_random_many(5)
+    a.use_device_step_counter()
+    a.step_random()
+    sd = a.state_dict()
+    assert sd["step_idx"] == 6
+    b = VecEnv(n, seed=0)                                   # host-side counter, other seed: everything comes from the dict
+    b.load_state_dict(sd)
+    assert b.step_idx == 6 and b.seed == seed and b.auto_reset
+    ra, ta = a.step_random()
+    rb, tb = b.step_random()
+    assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(ta, tb) and torch.equal(a.state, b.state)
+    c = VecEnv(n, seed=0)
+    c.use_device_step_counter()
+    c.load_state_dict(sd)                                   # device-side counter on the receiving end
+    c.step_random()
+    assert c.step_idx == 7 and torch.equal(c.state, b.state)
+    # Python-side inputs of step(): list of pairs, numpy int64 with junk, both equal the uint8 tensor path
+    e1, e2, e3 = VecEnv(4), VecEnv(4), VecEnv(4)
+    acts = [[0, 1], [9, 3], [-1, 2], [300, 4]]               # legal, out of range, negative, > 255: three noops
+    o1, r1, t1, _, _ = e1.step(acts)
+    o2, r2, t2, _, _ = e2.step(np.asarray(acts, dtype=np.int64))
+    o3, r3, t3, _, _ = e3.step(torch.tensor([[0, 1], [255, 3], [255, 2], [255, 4]], dtype=torch.uint8, device="cuda"))
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]) and torch.equal(o1[k], o3[k]), k
+    assert _np(e1.turn()).tolist() == [1, 0, 0, 0]
