@@ -583,8 +583,26 @@ def run(args):
     return rc
 
 
+def ensure_built():
+    """A fresh checkout has no libqttt_hip.so (built artefacts are not in the history): build it once, under a file
+    lock so that the N ranks of a launcher do not compile at the same time.  No GPU is touched here."""
+    lib = os.path.join(ROOT, "qtttgym_amd", "libqttt_hip.so")
+    if os.path.exists(lib):
+        return
+    import fcntl
+    with open(os.path.join(ROOT, "qtttgym_amd", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(lib):
+                import __graft_entry__ as g
+                g.build_hip()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def main():
     args = parse_args()
+    ensure_built()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.boards < 1 or args.total_boards < 0 \
             or args.fused_steps < 1 or (args.total_boards and args.total_boards < args.gpus):
         raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1, --total-boards >= --gpus")
