@@ -351,3 +351,26 @@ def test_make_moves_draws_like_a_loop_of_make_move_and_reports_each_exception(bi
     with pytest.raises(ValueError):
         Board.make_moves([a], [(2, 3), (4, 5)])
     assert Board.make_moves([], []) == []
+
+
+def test_the_binding_stub_of_integration_md_runs_as_written():
+    """INTEGRATION.md §2 shows the ctypes binding a maintainer of the reference would add: the code block is taken
+    from the document, pointed at the in-tree library and run against the first golden episodes."""
+    import os
+    import re
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# qtttgym/_hip\.py.*?)```", doc, flags=re.S).group(1)
+    code = code.replace('"libqttt_hip.so"', repr(os.path.join(root, "qtttgym_amd", "libqttt_hip.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    with np.load(os.path.join(root, "tests", "golden", "step_traces.npz")) as d:
+        acts, bits, board_last = d["actions"], d["bits"], d["board"]
+        rew, term = d["reward"], d["terminated"]
+    E, T = bits.shape
+    bb = ns["BatchedBoards"](E)
+    for t in range(T):
+        r, tm = bb.step(torch.from_numpy(acts[:, t].copy()).cuda(), torch.from_numpy(bits[:, t].copy()).cuda())
+        assert np.array_equal(r.cpu().numpy().view(np.uint32), rew[:, t].astype(np.float32).view(np.uint32)), t
+        assert np.array_equal(tm.cpu().numpy().astype(np.uint8), term[:, t]), t
