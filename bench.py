@@ -29,8 +29,10 @@ dist.shard_range: STRONG scaling, the JSON says so); `--boards B` is per GPU (we
 Legs.  At N = 1 the same JSON object carries `legs`: the other BASELINE configurations and modes measured
 in the same process on the same clock (HIP events, median region) — env.step replay at 4 096 / 262 144 /
 16 777 216 boards (the last cannot live in the 256 MB Infinity Cache), `gym` and `random` at 1 M, the fused
-random-policy multi-step kernel (qttt_step_random_many) at 4 096 / 262 144 / 1 M, and BASELINE config 5's
-unit (expand + node_info + rollout on 65 536 boards).  Each with us per launch, algorithmic bytes, frac.
+random-policy multi-step kernel (qttt_step_random_many) at 4 096 / 262 144 / 1 M, BASELINE config 5's
+unit (expand + node_info + rollout on 65 536 boards), and the kernels beside the step one by one at 1 M boards
+(observe, export, turn, check_win, node_info, expand, rollout, encode).  Each with us per launch, algorithmic
+bytes, frac.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -387,7 +389,50 @@ def run_legs(torch, dev, args):
     step_leg("random_fused_262144_boards", 262144, "random-fused", 128, 10)
     step_leg("random_fused_4096_boards", 4096, "random-fused", 128, 10)
     legs.append(config5_leg(torch, dev, args))
+    legs.extend(row_legs(torch, dev, args))
     return legs
+
+
+def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
+    """The kernels beside the step at 1 048 576 boards (SURVEY §8(f) rows and the cold paths), through VecEnv with
+    reused buffers, each timed on its own: us per launch, algorithmic bytes per board, fraction of the HBM spec."""
+    from qtttgym_amd import VecEnv
+    env = VecEnv(n, device=dev, seed=args.seed)
+    for _ in range(5):                                         # mid-game boards
+        env.step_raw(env.sample_actions())
+    sb = env.state.numel() // ((n + 63) // 64 * 64)
+    act = torch.randint(0, 36, (n,), dtype=torch.uint8, device=dev)
+    obs, ex, ni, cw, tn = env.observ(), env.export_boards(), env.node_info(), env.check_win(), env.turn()
+    xp, ro, enc = env.expand(act), env.rollout(), env.encode()
+    rows = [
+        ("observe", "observe_kernel", lambda: env.observ(), sb + 30, "hbm"),
+        ("export", "export_kernel", lambda: env.export_boards(out=ex), sb + 37, "hbm"),
+        ("turn", "export_kernel (n_moves only)", lambda: env.turn(out=tn), sb // 2 + 1, "launch"),
+        ("check_win", "check_win_kernel", lambda: env.check_win(out=cw), sb // 2 + 2, "launch"),
+        ("node_info", "node_info_kernel", lambda: env.node_info(out=ni), sb + 18, "valu (CPython tuple hash)"),
+        ("expand", "expand_kernel", lambda: env.expand(act, out=xp), sb + 1 + 2 * sb + 1 + 2 * 18, "valu (two steps + two tuple hashes)"),
+        ("rollout", "rollout_kernel", lambda: env.rollout(out=ro), sb + 2, "valu (8.3 plies per board)"),
+        ("encode", "encode_kernel", lambda: env.encode(out=enc), sb + 720 + 36, "hbm (write)"),
+    ]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = []
+    for name, kernel, fn, algo, bound in rows:
+        us = []
+        for _ in range(regions):
+            for _ in range(3):
+                fn()
+            e0.record()
+            for _ in range(K):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us.append(e0.elapsed_time(e1) * 1e3 / K)
+        u = median(us)
+        out.append({"name": "row_%s_1048576_boards" % name, "boards": n, "mode": "row", "kernel": kernel, "steps": K,
+                    "regions": regions, "us_per_launch": u, "best_region_us_per_launch": min(us),
+                    "algorithmic_bytes_per_board": algo, "achieved_GBps": algo * n / (u * 1e-6) / 1e9,
+                    "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": bound})
+    return out
 
 
 # SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 154 449 327 per dispatch of 1 048 576 boards x

@@ -95,10 +95,14 @@ def test_bench_default_line_carries_the_legs():
     assert time.time() - t0 < 120
     assert d["config"]["boards_per_gpu"] == 1 << 20 and d["config"]["mode"] == "replay"
     legs = {l["name"]: l for l in d["legs"]}
+    sb = d["config"]["state_bytes_per_board"]
     for name in ("config2_4096_boards", "config3_262144_boards", "beyond_infinity_cache_16777216_boards",
                  "gym_1048576_boards", "random_1048576_boards", "random_fused_1048576_boards",
                  "random_fused_262144_boards", "random_fused_4096_boards", "config5_expand_node_info_rollout_65536_boards"):
         assert name in legs, name
+    for name in ("observe", "export", "turn", "check_win", "node_info", "expand", "rollout", "encode"):
+        assert "row_%s_1048576_boards" % name in legs, name
+    assert legs["row_export_1048576_boards"]["algorithmic_bytes_per_board"] == sb + 37
     for l in d["legs"]:
         assert l["regions"] >= 5 and 0 < l["frac"] < 1 and l["achieved_GBps"] > 0
         if "us_per_step" in l:
