@@ -411,7 +411,7 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
         ("check_win", "check_win_kernel", lambda: env.check_win(out=cw), sb // 2 + 2, "launch"),
         ("node_info", "node_info_kernel", lambda: env.node_info(out=ni), sb + 18, "valu (CPython tuple hash)"),
         ("expand", "expand_kernel", lambda: env.expand(act, out=xp), sb + 1 + 2 * sb + 1 + 2 * 18, "valu (two steps + two tuple hashes)"),
-        ("rollout", "rollout_kernel", lambda: env.rollout(out=ro), sb + 2, "valu (8.3 plies per board)"),
+        ("rollout", "rollout_kernel", lambda: env.rollout(out=ro), sb + 2, "valu (playouts to the end from boards five plies deep)"),
         ("encode", "encode_kernel", lambda: env.encode(out=enc), sb + 720 + 36, "hbm (write)"),
     ]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
