@@ -452,23 +452,33 @@ def config5_leg(torch, dev, args, n=65536, K=50):
     for _ in range(4):
         env.step_raw(env.sample_actions())
     act = torch.randint(0, 36, (n,), dtype=torch.uint8, device=dev)
-    ex, ni, ro = env.expand(act), env.node_info(), env.rollout()
+    ex, ni, ro, rm = env.expand(act), env.node_info(), env.rollout(), env.rollout_many(10)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(unit):
+        us = []
+        for _ in range(8):
+            for _ in range(5):
+                unit()
+            e0.record()
+            for _ in range(K):
+                unit()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us.append(e0.elapsed_time(e1) * 1e3 / K)
+        return us
 
     def unit():
         env.expand(act, out=ex)
         env.node_info(out=ni)
         env.rollout(out=ro)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    us = []
-    for _ in range(8):
-        for _ in range(5):
-            unit()
-        e0.record()
-        for _ in range(K):
-            unit()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        us.append(e0.elapsed_time(e1) * 1e3 / K)
+
+    def unit10():                                  # mcts.py:131,170-176: num_simulations = 10 playouts per leaf
+        env.expand(act, out=ex)
+        env.node_info(out=ni)
+        env.rollout_many(10, out=rm)
+    us = timed(unit)
+    us10 = timed(unit10)
     sb = env.state.numel() // ((n + 63) // 64 * 64)
     # expand: state + action in, two children + n_children + per-child winner/terminal/legal/key out;
     # node_info: state in, 18 B out; rollout: state in, result + plies out
@@ -477,6 +487,7 @@ def config5_leg(torch, dev, args, n=65536, K=50):
     return {"name": "config5_expand_node_info_rollout_65536_boards", "boards": n, "mode": "mcts-unit",
             "kernel": "expand_kernel + node_info_kernel + rollout_kernel", "steps": K, "regions": len(us),
             "us_per_unit": u, "best_region_us_per_unit": min(us), "expansions_per_s": n / (u * 1e-6),
+            "us_per_unit_with_10_playouts_per_leaf": median(us10), "playouts_per_s_10_per_leaf": 10 * n / (median(us10) * 1e-6),
             "algorithmic_bytes_per_board_unit": algo, "achieved_GBps": algo * n / (u * 1e-6) / 1e9,
             "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "launch + valu (3 kernels, 65 536 boards each)"}
 

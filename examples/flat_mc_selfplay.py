@@ -32,11 +32,9 @@ def search_actions(env, sims, sweep):
     nch = out["n_children"].to(torch.float32)                       # 0 illegal, 1, or 2 (collapse)
     value = torch.zeros(G * 36, device=dev)
     for c, child in enumerate((out["child0"], out["child1"])):
-        tot = torch.zeros(G * 36, device=dev)
-        ro = None
-        for s in range(sims):
-            ro = child.rollout(step_idx0=100 + 16 * (sweep * sims + s), out=ro)   # the same two buffers every playout
-            tot += ro[0].to(torch.float32)
+        # `sims` playouts per child in ONE launch (mcts.py:170-176: the num_simulations loop), one lane per playout
+        res = child.rollout_many(sims, step_idx0=100 + 16 * sweep * sims)
+        tot = res.to(torch.float32).sum(dim=1)
         value += torch.where(nch > c, tot / sims, torch.zeros_like(tot))
     value = value / nch.clamp(min=1)                                # both collapse branches equally likely
     value = torch.where(nch > 0, value, torch.full_like(value, -2.0))

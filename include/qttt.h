@@ -187,6 +187,14 @@ int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *
 int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
                  int8_t *result, uint8_t *plies, void *final_state, int64_t n, void *stream);
 
+/* MCTS._rollout's simulation loop (mcts.py:170-176: num_simulations playouts of one leaf) for n boards in ONE launch:
+ * result[i, s] and plies[i, s] (nullable) are what qttt_rollout(step_idx0 + s * QTTT_SIM_STRIDE) gives for board i,
+ * s = 0 .. n_sims - 1; one lane per (board, simulation), so 65 536 leaves x 10 simulations fill the chip.
+ *   result i8[n, n_sims], plies u8[n, n_sims] */
+#define QTTT_SIM_STRIDE 16u      /* a playout has at most 9 plies: simulations use disjoint step indices */
+int qttt_rollout_many(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
+                      int32_t n_sims, int8_t *result, uint8_t *plies, int64_t n, void *stream);
+
 /* GameState.to_vector (mcts.py:67-85) -> vec f32[n,18,10]; action_mask (mcts.py:87-91) ->
  * mask u8[n,36] (nullable).  The reference builds float64; values are 0, 1 and 1/3 rounded to f32. */
 int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *stream);

@@ -11,6 +11,7 @@ ABI_VERSION = 3
 FLAG_AUTO_RESET = 1
 FLAG_FUSED = 2
 BOARD_RECORD_BYTES = 64
+SIM_STRIDE = 16
 OP_MAKE_MOVE, OP_UPDATE_QSTRUCTS, OP_CHECK_WIN = 0, 1, 2
 
 class EnvRecord(ctypes.Structure):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_expand": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_rollout": (_i32, [_vp, _u64, _u32, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_rollout_many": (_i32, [_vp, _u64, _u32, _i64, _i32, _vp, _vp, _i64, _vp]),
     "qttt_encode": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_set_tuning": (_i32, [_i32, _i32]),
     "qttt_step_launch_shape": (_i32, [_i64, _u32, _i32, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

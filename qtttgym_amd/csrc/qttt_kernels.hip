@@ -527,6 +527,18 @@ int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t b
     return launch_status();
 }
 
+int qttt_rollout_many(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
+                      int32_t n_sims, int8_t *result, uint8_t *plies, int64_t n, void *stream) {
+    if (n < 0 || board_offset < 0 || n_sims < 0) return QTTT_ERR_SIZE;
+    if (n == 0 || n_sims == 0) return 0;
+    if (!state || !result) return QTTT_ERR_NULL;
+    Planes p = planes(const_cast<void *>(state), n);
+    const int64_t lanes = n * (int64_t)n_sims;
+    hipLaunchKernelGGL(rollout_many_kernel, dim3(grid_for(lanes)), dim3(QTTT_BLOCK), 0, (hipStream_t)stream,
+                       p.P, p.Q, (u64)seed, step_idx0, (u64)board_offset, (u32)n_sims, result, plies, lanes);
+    return launch_status();
+}
+
 int qttt_encode(const void *state, float *vec, uint8_t *mask, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;

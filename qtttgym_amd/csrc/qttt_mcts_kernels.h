@@ -145,6 +145,23 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(
 // MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
 // random moves to the end with the board in registers.  Ply p uses the counter hash of
 // (seed, board id, step_idx0 + p) exactly like qttt_sample_actions + qttt_step would.
+// one playout of the board in (P0, P1, Q0, Q1) to the end; returns the number of plies played
+__device__ __forceinline__ u32 playout(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 id, u64 seed, u32 step_idx0,
+                                       const uint8_t *lut, const uint8_t *plut, const uint8_t *nth9) {
+    u32 played = 0;
+    for (u32 p = 0; p < 9u; ++p) {
+        const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
+        if ((P1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
+        const u64 key = launch_key(seed, step_idx0 + p);
+        const u32 h1 = lowbias32(id ^ (u32)key);
+        const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+        const u32 act = policy_action_nth9(plut, nth9, empty, h2);   // the k-th legal pair, squares a < b
+        step_core<false, true>(P0, P1, Q0, Q1, act, h1 >> 31, lut);   // legal and sorted
+        played += 1u;
+    }
+    return played;
+}
+
 __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     const u64 *pP, const u64 *pQ, u64 seed, u32 step_idx0, u64 board_offset,
     int8_t *result, uint8_t *plies, u64 *fP, u64 *fQ, int64_t n) {
@@ -158,24 +175,41 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
-    const u32 id = fold_id(board_offset + (u64)i);
-    u32 played = 0;
-    for (u32 p = 0; p < 9u; ++p) {
-        const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
-        if ((P1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
-        const u64 key = launch_key(seed, step_idx0 + p);
-        const u32 h1 = lowbias32(id ^ (u32)key);
-        const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
-        const u32 act = policy_action_nth9(plut, nth9, empty, h2);   // the k-th legal pair, squares a < b
-        step_core<false, true>(P0, P1, Q0, Q1, act, h1 >> 31, lut);   // legal and sorted
-        played += 1u;
-    }
+    const u32 played = playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed, step_idx0, lut, plut, nth9);
     const u64 oP = (u64)P0 | ((u64)P1 << 32), oQ = (u64)Q0 | ((u64)Q1 << 32);
     int w, t;
     lite_update_winner(lite_unpack(oP), lut, w, t);
     result[i] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));       // MCTS._reward, mcts.py:200-209
     plies[i] = (uint8_t)played;
     if (fP) { fP[i] = oP; fQ[i] = oQ; }
+}
+
+// MCTS._rollout's `for _ in range(self.num_simulations): r = self._simulate(leaf)` (mcts.py:170-176) in ONE launch:
+// lane j plays simulation j % n_sims of board j / n_sims, with the step indices of qttt_rollout(step_idx0 +
+// sim * QTTT_SIM_STRIDE) — so a batch too small to fill the chip (65 536 leaves) still does, n_sims times over.
+// Outputs [n, n_sims], contiguous in lane order.
+__global__ __launch_bounds__(QTTT_BLOCK) void rollout_many_kernel(
+    const u64 *pP, const u64 *pQ, u64 seed, u32 step_idx0, u64 board_offset, u32 n_sims,
+    int8_t *result, uint8_t *plies, int64_t n_lanes) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    __shared__ uint8_t nth9[512 * 9];
+    const int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
+    const int64_t jl = j < n_lanes ? j : 0;
+    const int64_t i = jl / n_sims;                        // board
+    const u32 sim = (u32)(jl - i * n_sims);
+    const u64 P = pP[i], Q = pQ[i];                       // n_sims neighbouring lanes read the same 16 bytes
+    fill_policy_lut<QTTT_BLOCK>(plut);
+    fill_nth9<QTTT_BLOCK>(nth9);
+    fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
+    if (j >= n_lanes) return;
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
+    const u32 played = playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed, step_idx0 + sim * QTTT_SIM_STRIDE,
+                               lut, plut, nth9);
+    int w, t;
+    lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, t);
+    result[j] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));
+    if (plies) plies[j] = (uint8_t)played;
 }
 
 // GameState.to_vector (mcts.py:67-85) as f32[18][10] and action_mask (mcts.py:87-91).

@@ -524,6 +524,29 @@ class VecEnv:
         _native.check(rc, "qttt_rollout")
         return (result, plies, final) if return_final else (result, plies)
 
+    def rollout_many(self, n_sims, step_idx0=None, with_plies=False, out=None):
+        """MCTS._rollout's simulation loop (mcts.py:170-176: num_simulations playouts from each leaf) in ONE launch,
+        one lane per (board, simulation): result i8[N, n_sims] (+1 / -1 / 0 per MCTS._reward), optionally plies
+        u8[N, n_sims].  Column s equals rollout(step_idx0 + s * 16).  `out` = what an earlier call returned."""
+        n, S, dev = self.num_envs, int(n_sims), self.device
+        if S < 1:
+            raise ValueError("n_sims must be >= 1")
+        if step_idx0 is None:
+            step_idx0 = self.step_idx
+        if out is None:
+            with torch.cuda.device(dev):
+                result = torch.empty((n, S), dtype=torch.int8, device=dev)
+                plies = torch.empty((n, S), dtype=torch.uint8, device=dev) if with_plies else None
+        else:
+            result, plies = (out if with_plies else (out, None))
+            _check_out(result, torch.int8, (n, S), self.state.device, "out result")
+            if with_plies:
+                _check_out(plies, torch.uint8, (n, S), self.state.device, "out plies")
+        rc = self._launch(self._lib.qttt_rollout_many, self.state.data_ptr(), self.seed, int(step_idx0), self.board_offset,
+                          S, result.data_ptr(), _ptr(plies), n, self._stream())
+        _native.check(rc, "qttt_rollout_many")
+        return (result, plies) if with_plies else result
+
     def encode(self, with_mask=True, out=None):
         """GameState.to_vector (mcts.py:67-85) as f32[N,18,10] and action_mask (mcts.py:87-91) as
         bool[N,36], without leaving the GPU.  `out` = what an earlier call returned, to be overwritten."""

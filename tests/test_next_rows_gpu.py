@@ -226,3 +226,36 @@ def test_outcome_distribution_matches_reference_statistics():
     r = result.cpu().numpy()
     both = (p1 > 0) & (p2 > 0)
     assert np.array_equal(r[both], np.where(p1[both] < p2[both], 1, -1))
+
+
+@pytest.mark.parametrize("n,sims", [(1, 1), (3, 7), (1000, 10), (65536, 10), (4099, 33)])
+def test_rollout_many_columns_equal_single_rollouts(n, sims):
+    """qttt_rollout_many = MCTS._rollout's num_simulations loop (mcts.py:170-176) in one launch: column s is
+    qttt_rollout(step_idx0 + 16 s) — which the tests above hold against the oracle's playout loop."""
+    from qtttgym_amd import VecEnv
+    env = VecEnv(n, seed=19, board_offset=5 * n)
+    rng = np.random.default_rng(n)
+    depth = torch.from_numpy(rng.integers(0, 8, n).astype(np.uint8)).cuda()
+    for t in range(7):                                                  # parents at mixed depths (some finished)
+        a = env.sample_actions()
+        a[depth <= t] = 0
+        env.step_raw(a)
+    s0 = 123
+    res, pl = env.rollout_many(sims, step_idx0=s0, with_plies=True)
+    assert res.shape == (n, sims) and pl.shape == (n, sims)
+    for s in range(sims):
+        r1, p1 = env.rollout(step_idx0=s0 + 16 * s)
+        assert torch.equal(res[:, s], r1) and torch.equal(pl[:, s], p1), s
+    only = env.rollout_many(sims, step_idx0=s0)
+    assert torch.equal(only, res)
+    res.zero_()
+    assert env.rollout_many(sims, step_idx0=s0, out=res) is res and torch.equal(res, only)
+    if n >= 1000:                                                       # simulations of one leaf differ, the mean is a value estimate
+        live = pl[:, 0] > 0
+        assert bool((res[live].to(torch.float32).std(dim=1) > 0).any())
+    with pytest.raises(ValueError):
+        env.rollout_many(0)
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    assert L.qttt_rollout_many(env.state.data_ptr(), 1, 0, 0, 4, None, None, n, s) == -1
+    assert L.qttt_rollout_many(env.state.data_ptr(), 1, 0, 0, -1, res.data_ptr(), None, n, s) == -2
+    assert L.qttt_rollout_many(env.state.data_ptr(), 1, 0, 0, 0, res.data_ptr(), None, n, s) == 0

@@ -59,6 +59,15 @@ def main():
         plies = float(pl.float().mean())
         out.append({"row": "rollout_from_empty_board", "boards": n, "us": t * 1e6, "playouts_per_s": n / t,
                     "mean_plies": plies, "env_steps_per_s": n * plies / t})
+    # MCTS._rollout's simulation loop (mcts.py:170-176): 10 playouts per leaf, one launch against ten
+    n = 65536
+    env = midgame(n, 3)
+    rm = env.rollout_many(10)
+    ro = env.rollout()
+    t_many = timed(lambda: env.rollout_many(10, out=rm), reps=20)
+    t_loop = timed(lambda: [env.rollout(step_idx0=16 * k, out=ro) for k in range(10)], reps=10)
+    out.append({"row": "rollout_10_simulations_per_leaf", "boards": n, "us_one_launch": t_many * 1e6,
+                "us_ten_launches": t_loop * 1e6, "playouts_per_s_one_launch": 10 * n / t_many})
     n = 1 << 20
     env = midgame(n, 5)
     vec = torch.empty((n, 18, 10), dtype=torch.float32, device="cuda")
