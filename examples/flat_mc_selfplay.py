@@ -23,10 +23,8 @@ from qtttgym_amd.actions import action36_to_pairs  # noqa: E402  (ind2move for a
 def search_actions(env, sims, sweep):
     """Best action36 per game for the side to move (as P1: maximise the playout result)."""
     G, dev = env.num_envs, env.device
-    # one row per (game, action): replicate the G states 36 times along the board axis
-    ex = env.export_boards()
-    rep = VecEnv(G * 36, device=dev, seed=env.seed + 1000 + sweep)
-    rep.import_boards(*(ex[k].repeat_interleave(36, dim=0) for k in ("moves", "n_moves", "board", "qmask", "n_q")))
+    # one row per (game, action): every state lined up 36 times (the packed planes are indexed, nothing is unpacked)
+    rep = env.take(torch.arange(G, device=dev).repeat_interleave(36), seed=env.seed + 1000 + sweep)
     act = torch.arange(36, dtype=torch.uint8, device=dev).repeat(G)
     out = rep.expand(act)
     nch = out["n_children"].to(torch.float32)                       # 0 illegal, 1, or 2 (collapse)

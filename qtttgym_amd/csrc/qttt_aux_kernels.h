@@ -269,8 +269,14 @@ __device__ __forceinline__ void cold_from_attrs(const uint8_t *moves, u32 n_move
     const u32 nq = min(n_q, 4u);
     s.comps = 0;
     for (u32 k = 0; k < nq; ++k) s.comps |= (u64)(qmask[k] & 0x1FFu) << (9u * k);
-    // root every tree of live edges: grow from the lowest square of each tree
+    // root every tree of live edges: grow from the lowest square of each tree.  The given qstructs name the trees
+    // (their lowest squares start as roots, all trees grow at once: passes = the deepest tree's depth); whatever
+    // they do not cover — attributes a caller assigned inconsistently — is picked up tree by tree below
     u32 rooted = 0;
+    for (u32 k = 0; k < nq; ++k) {
+        const u32 m = (u32)(s.comps >> (9u * k)) & 0x1FFu & ~s.cl;
+        rooted |= m & (0u - m);
+    }
     for (int pass = 0; pass < 9; ++pass) {
         bool grew = false;
         u32 cand = 0;

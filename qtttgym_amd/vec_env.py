@@ -439,6 +439,23 @@ class VecEnv:
         env._bind_outputs()
         return env
 
+    def take(self, index, seed=None, auto_reset=None, board_offset=None):
+        """A new VecEnv holding boards self[index] (any int64 index tensor; repeats allowed): the batched form of
+        `copy.deepcopy(node)` + attribute assignment in MCTS._step (mcts.py:236-241) — e.g.
+        `env.take(torch.arange(N).repeat_interleave(36))` lines every leaf up 36 times for one expand() over all
+        its actions.  Pure indexing of the two packed planes; nothing is unpacked."""
+        idx = torch.as_tensor(index, device=self.state.device).to(torch.int64).reshape(-1)
+        m = int(idx.numel())
+        lib = self._lib
+        planes = self.state.view(torch.int64).view(2, -1)
+        with torch.cuda.device(self.device):
+            st = torch.zeros(int(lib.qttt_state_bytes(m)), dtype=torch.uint8, device=self.device)
+        if m:
+            st.view(torch.int64).view(2, -1)[:, :m] = planes[:, idx]
+        return VecEnv.from_state(st, m, seed=self.seed if seed is None else seed,
+                                 auto_reset=self.auto_reset if auto_reset is None else auto_reset,
+                                 board_offset=self.board_offset if board_offset is None else board_offset)
+
     def node_info(self, out=None):
         """GameState bookkeeping per board (mcts.py:20-27,52-65,93-94): winner i8 (1/0/-1 = True/
         False/None), terminal bool, legal int64 (bit a = action a legal), key int64 (= Python's

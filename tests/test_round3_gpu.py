@@ -563,3 +563,24 @@ def test_checkpoint_round_trip_with_the_device_step_counter_and_python_inputs():
     for k in o1:
         assert torch.equal(o1[k], o2[k]) and torch.equal(o1[k], o3[k]), k
     assert _np(e1.turn()).tolist() == [1, 0, 0, 0]
+
+
+def test_take_lines_boards_up_without_unpacking_them():
+    from qtttgym_amd import VecEnv
+    n = 1000
+    env = VecEnv(n, seed=8)
+    for _ in range(5):
+        env.step_raw(env.sample_actions())
+    idx = torch.tensor([3, 3, 999, 0, 3, 500], device="cuda")
+    sub = env.take(idx)
+    ex, sx = env.export_boards(), sub.export_boards()
+    for k in ex:
+        assert torch.equal(sx[k], ex[k][idx]), k
+    assert sub.num_envs == 6 and sub.seed == env.seed
+    rep = env.take(torch.arange(n, device="cuda").repeat_interleave(36))
+    assert rep.num_envs == 36 * n
+    out = rep.expand(torch.arange(36, dtype=torch.uint8, device="cuda").repeat(n))
+    legal = env.node_info()["legal"]
+    bits = ((legal[:, None] >> torch.arange(36, device="cuda")[None, :]) & 1).bool().reshape(-1)
+    assert torch.equal(out["n_children"] > 0, bits)                      # an action has children iff node_info calls it legal
+    assert env.take(torch.empty(0, dtype=torch.int64, device="cuda")).num_envs == 0

@@ -91,6 +91,10 @@ def main():
                                                ex["board"].data_ptr(), ex["qmask"].data_ptr(), ex["n_q"].data_ptr(), n, s), reps=20)
     out.append({"row": "export", "boards": n, "us": t * 1e6, "us_out_reuse": t_out * 1e6, "us_kernel_only": t_raw * 1e6,
                 "output_bytes_per_board": 37})
+    env2 = VecEnv(n, seed=9)
+    t_imp = timed(lambda: env2._lib.qttt_import(env2.state.data_ptr(), ex["moves"].data_ptr(), ex["n_moves"].data_ptr(),
+                                                ex["board"].data_ptr(), ex["qmask"].data_ptr(), ex["n_q"].data_ptr(), n, s), reps=20)
+    out.append({"row": "import", "boards": n, "us_kernel_only": t_imp * 1e6, "input_bytes_per_board": 37})
     t = timed(lambda: env.check_win(), reps=10)
     p1, p2 = env.check_win()
     t_raw = timed(lambda: env._lib.qttt_check_win(env.state.data_ptr(), p1.data_ptr(), p2.data_ptr(), n, s), reps=20)
