@@ -300,17 +300,154 @@ __device__ __forceinline__ void cold_from_attrs(const uint8_t *moves, u32 n_move
     s.done = (p1 > 0 || p2 > 0 || s.n > 8u) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(QTTT_COLD_BLOCK) void import_kernel(
-    u64 *pP, u64 *pQ, const uint8_t *moves, const uint8_t *n_moves, const int8_t *board,
-    const uint16_t *qmask, const uint8_t *n_q, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Cold s;
-    cold_from_attrs(moves + i * 18, n_moves[i], board + i * 9, qmask + i * 4, n_q[i], s);
+// ---------------------------------------------------------------------------------------------------------
+// qttt_import for batches: the inverse of export_kernel.  The five input arrays come in through LDS tiles laid out
+// like the inputs (16-byte global loads by the wave that owns the rows), a lane reads its board's rows with wide
+// LDS loads and builds the packed words directly:
+//   * classical mask and round codes from the nine board bytes, nibble-parallel;
+//   * the x = lo ^ hi nibbles of Q0 from the (lo, hi) byte pairs (padding 255 ^ 255 and an autofill move (idx, idx)
+//     give 0 by themselves);
+//   * the explicit autofill move (board.py:22-25) stripped back to the implicit form;
+//   * the rooted forest: the un-collapsed moves are inserted in round order exactly as the step inserts a move —
+//     re-root the tree of one end (path reversal, the step's own walk), hang it under the other end;
+//   * qstructs from the caller's masks as they are; done = a line or nine moves (env.py:51).
+// Valid (reachable) attribute sets give a state whose export is the input again; anything else gives some state
+// without faults or unbounded loops (the walk is bounded by nine nodes).  The single-record Board façade keeps the
+// generic cold_from_attrs path.
+template <int BLOCK>
+__device__ inline void tile_copy_in(uint8_t *tile16, const uint8_t *gsrc, u32 nbytes) {
+    uint8_t *dst = tile16 + obs_phase(gsrc);
+    for (u32 k = threadIdx.x; k < nbytes; k += BLOCK) dst[k] = gsrc[k];
+}
+__device__ inline void wave_copy_in16(uint8_t *tile16, const uint8_t *gsrc, u32 begin, u32 end) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32x4 *gq = reinterpret_cast<const u32x4 *>(gsrc);
+    u32x4 *sq = reinterpret_cast<u32x4 *>(tile16);
+    const u32 q0 = begin >> 4, q1 = end >> 4;                       // begin is a multiple of 16
+    for (u32 k = q0 + lane; k < q1; k += 64u) sq[k] = __builtin_nontemporal_load(&gq[k]);
+    const u32 kb = (q1 << 4) + lane;                                 // < 16 bytes left
+    if (kb < end) tile16[kb] = gsrc[kb];
+}
+
+// low nibbles of the four bytes of x -> 16 bits (byte k -> nibble k)
+__device__ __forceinline__ u32 nibbles_of_bytes(u32 x) {
+    const u32 y = (x | (x >> 4)) & 0x00FF00FFu;
+    return (y | (y >> 8)) & 0xFFFFu;
+}
+// (lo, hi) byte pairs of four rounds e0..e0+3 -> x nibbles in the order Q0 wants: x_e0 in the highest nibble
+__device__ __forceinline__ u32 x_nibbles_of_pairs(u64 m) {
+    const u64 xr = m ^ (m >> 8);                                     // bytes 0, 2, 4, 6 = lo ^ hi
+    const u32 a = (u32)xr & 0x000F000Fu, b = (u32)(xr >> 32) & 0x000F000Fu;
+    return (((a << 12) | (a >> 8)) & 0xFF00u) | (((b << 4) | (b >> 16)) & 0x00FFu);
+}
+
+__device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, u64 b07, u32 b8, u64 qm, u32 nq,
+                                             const uint8_t *lut, u64 &Pout, u64 &Qout) {
+    const u32 n = min(nmv, 9u);
+    // ---- Board.board: classical mask + codes (15 - round), squares 0..7 nibble-parallel
+    const u32 blo = (u32)b07, bhi = (u32)(b07 >> 32);
+    const u32 clo = (~blo >> 7) & 0x01010101u, chi = (~bhi >> 7) & 0x01010101u;         // 1 per classical byte
+    u32 cl = ((clo * 0x01020408u) >> 24) | (((chi * 0x01020408u) >> 24) << 4) | ((b8 & 0x80u) ? 0u : 0x100u);
+    u32 W = nibbles_of_bytes(~blo & 0x0F0F0F0Fu & ((clo << 8) - clo)) |
+            (nibbles_of_bytes(~bhi & 0x0F0F0F0Fu & ((chi << 8) - chi)) << 16);
+    u32 c8 = (b8 & 0x80u) ? 0u : (~b8 & 0xFu);
+    // ---- Board.moves: x nibbles; the last move (an explicit autofill move is stripped: board.py:22-25 is implicit here)
+    const u32 last = n - 1u;                                             // (n == 0: nothing below looks at it)
+    const u32 pair = last >= 8u ? m8 : (u32)((last < 4u ? m03 : m47) >> (16u * (last & 3u))) & 0xFFFFu;
+    const u32 l_lo = pair & 0xFFu, l_hi = (pair >> 8) & 0xFFu;
+    const bool is_auto = n >= 1u && l_lo == l_hi && l_lo < 9u;
+    const u32 n_real = is_auto ? n - 1u : n;
+    if (is_auto) {
+        cl &= ~(1u << l_lo);
+        if (l_lo < 8u) W &= ~(0xFu << (4u * l_lo)); else c8 = 0u;
+    }
+    const u32 Xn = (x_nibbles_of_pairs(m03) << 16) | x_nibbles_of_pairs(m47);   // nibble 7 - e = x of round e
+    const u32 x8 = n_real == 9u ? ((m8 ^ (m8 >> 8)) & 0xFu) : 0u;
+    u32 Q0 = __builtin_amdgcn_alignbit(Xn, Xn, 30u) ^ rotr32(x8, 2u);             // rotl 2; round 8's x onto round 0's nibble
+    const u32 last_x = n_real == 0u ? 0u : (n_real == 9u ? x8 : (Xn >> (4u * (8u - n_real))) & 0xFu);
+    // ---- Board.qstructs as given: 4 x 9 bits, list order
+    const u32 nqc = min(nq, 4u);
+    const u64 comps_all = (u64)((u32)qm & 0x1FFu) | ((u64)((u32)(qm >> 16) & 0x1FFu) << 9) |
+                          ((u64)((u32)(qm >> 32) & 0x1FFu) << 18) | ((u64)((u32)(qm >> 48) & 0x1FFu) << 27);
+    const u64 comps = nqc >= 4u ? comps_all : comps_all & ((1ull << (9u * nqc)) - 1ull);
+    // ---- the rooted forest: insert the un-collapsed moves in round order (the step's own path reversal)
+    u64 P = ((u64)W << 2) | ((u64)c8 << 34);
+#pragma unroll
+    for (u32 t = 0; t < 8u; ++t) {
+        const u32 pr = (u32)((t < 4u ? m03 : m47) >> (16u * (t & 3u))) & 0xFFFFu;
+        const u32 lo = pr & 0xFFu, hi = pr >> 8;
+        if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u) {
+            u32 v4 = hi * 4u, prev4 = (15u - t) * 4u;                    // hi becomes the child end of move t
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {                                // (rolled: 23.0 against 21.3 us per 1 M boards)
+                const u32 tt = (u32)(P >> v4);
+                const u32 ec4 = tt & 0x3Cu;
+                P ^= (u64)((tt ^ prev4) & 0x3Cu) << v4;                  // sq[v] = prev
+                if (ec4 == 0u) break;                                    // v was the root
+                v4 ^= rotr32(Q0, ec4) & 0x3Cu;
+                prev4 = ec4;
+            }
+        }
+    }
+    u32 P0 = (u32)P, P1 = (u32)(P >> 32) & 0x3Fu;
+    P1 |= (n_real << P1_N_SHIFT) | (((u32)(comps >> 32) & 0xFu) << P1_CHI_SHIFT) | (last_x << P1_LX_SHIFT) | (cl << P1_CL_SHIFT);
+    // ---- done = a completed line or nine moves (env.py:51), as the step computes it (qttt_step_core.h)
+    const u32 par4 = P0 & 0x44444444u;
+    const u32 even4 = __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
+                      (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 << 8) & 0x400u);
+    const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;
+    const u32 pc = (u32)__builtin_popcount(cl4);
+    const u32 O4 = cl4 & ~even4;
+    const u32 X4 = pc >= 8u ? (O4 ^ 0x7FCu) : (cl4 & even4);
+    const u32 win = (u32)lut[X4] | (u32)lut[O4];
+    P1 |= ((win | (pc & 8u)) << 28) & P1_DONE;
+    Pout = (u64)P0 | ((u64)P1 << 32);
+    Qout = (u64)Q0 | ((u64)(u32)comps << 32);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void import_kernel(u64 *pP, u64 *pQ, ExpOut in, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[exp_lds_bytes(BLOCK)];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    const int64_t base = (int64_t)blockIdx.x * BLOCK;
+    const u32 valid = (u32)min((int64_t)BLOCK, n - base);
+    const uint8_t *g_mv = in.moves + base * 18, *g_bd = reinterpret_cast<const uint8_t *>(in.board) + base * 9;
+    const uint8_t *g_qm = reinterpret_cast<const uint8_t *>(in.qmask) + base * 8, *g_nm = in.n_moves + base, *g_nq = in.n_q + base;
+    uint8_t *l_mv = tile, *l_bd = l_mv + obs_tile_bytes(BLOCK, 18), *l_qm = l_bd + obs_tile_bytes(BLOCK, 9);
+    uint8_t *l_nm = l_qm + obs_tile_bytes(BLOCK, 8), *l_nq = l_nm + obs_tile_bytes(BLOCK, 1);
+    const uintptr_t all = (uintptr_t)g_mv | (uintptr_t)g_bd | (uintptr_t)g_qm | (uintptr_t)g_nm | (uintptr_t)g_nq;
+    fill_line_lut_nosync<BLOCK>(lut);
+    if ((all & 15u) == 0u) {                                             // every wave fetches the rows it will read
+        const u32 w0 = threadIdx.x & ~63u, w1 = min(w0 + 64u, valid);
+        if (w0 < valid) {
+            wave_copy_in16(l_mv, g_mv, w0 * 18u, w1 * 18u);
+            wave_copy_in16(l_bd, g_bd, w0 * 9u, w1 * 9u);
+            wave_copy_in16(l_qm, g_qm, w0 * 8u, w1 * 8u);
+            wave_copy_in16(l_nm, g_nm, w0, w1);
+            wave_copy_in16(l_nq, g_nq, w0, w1);
+        }
+    } else {
+        tile_copy_in<BLOCK>(l_mv, g_mv, valid * 18u);
+        tile_copy_in<BLOCK>(l_bd, g_bd, valid * 9u);
+        tile_copy_in<BLOCK>(l_qm, g_qm, valid * 8u);
+        tile_copy_in<BLOCK>(l_nm, g_nm, valid);
+        tile_copy_in<BLOCK>(l_nq, g_nq, valid);
+    }
+    __syncthreads();                                                     // the line table (and, misaligned, the tiles)
+    const u32 b = threadIdx.x;
+    if (b >= valid) return;
+    const uint8_t *r_mv = l_mv + obs_phase(g_mv) + b * 18u, *r_bd = l_bd + obs_phase(g_bd) + b * 9u;
+    u64 m03, m47, b07, qm;
+    uint16_t m8;
+    __builtin_memcpy(&m03, r_mv, 8);
+    __builtin_memcpy(&m47, r_mv + 8, 8);
+    __builtin_memcpy(&m8, r_mv + 16, 2);
+    __builtin_memcpy(&b07, r_bd, 8);
+    __builtin_memcpy(&qm, l_qm + obs_phase(g_qm) + b * 8u, 8);
     u64 P, Q;
-    cold_pack(s, P, Q);
-    pP[i] = P;
-    pQ[i] = Q;
+    import_board(m03, m47, m8, (l_nm + obs_phase(g_nm))[b], b07, r_bd[8], qm, (l_nq + obs_phase(g_nq))[b], lut, P, Q);
+    store_stream(&pP[base + b], P);
+    store_stream(&pQ[base + b], Q);
 }
 
 // Board.make_move / update_qstructs / check_win (board.py:9-115) on caller-assigned attributes, one

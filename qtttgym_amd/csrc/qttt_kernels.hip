@@ -431,8 +431,10 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
     if (n == 0) return 0;
     if (!state || !moves || !n_moves || !board || !qmask || !n_q) return QTTT_ERR_NULL;
     Planes p = planes(state, n);
-    hipLaunchKernelGGL(import_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       p.P, p.Q, moves, n_moves, board, qmask, n_q, n);
+    const ExpOut in = {const_cast<uint8_t *>(moves), const_cast<uint8_t *>(n_moves), const_cast<int8_t *>(board),
+                       const_cast<uint16_t *>(qmask), const_cast<uint8_t *>(n_q)};
+    hipLaunchKernelGGL((import_kernel<QTTT_COLD_BLOCK>), dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
+                       p.P, p.Q, in, n);
     return launch_status();
 }
 
