@@ -584,3 +584,59 @@ def test_take_lines_boards_up_without_unpacking_them():
     bits = ((legal[:, None] >> torch.arange(36, device="cuda")[None, :]) & 1).bool().reshape(-1)
     assert torch.equal(out["n_children"] > 0, bits)                      # an action has children iff node_info calls it legal
     assert env.take(torch.empty(0, dtype=torch.int64, device="cuda")).num_envs == 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 100003])
+def test_import_tiles_round_trip_misaligned_views_and_garbage(n):
+    """qttt_import (LDS tiles, nibble-parallel unpack, round-order insertion): export -> import -> export is the
+    identity at every depth incl. finished games, from whole tensors and from views offset by one board (every
+    alignment phase); the imported boards then step exactly like the originals; arbitrary bytes neither fault nor hang."""
+    from qtttgym_amd import VecEnv
+    seed = 5 + n
+    env = VecEnv(n, seed=seed)
+    rng = np.random.default_rng(n)
+    depth = torch.from_numpy(rng.integers(0, 11, n).astype(np.uint8)).cuda()
+    a = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(10):
+        env.sample_actions(out=a)
+        a[depth <= t] = 0
+        env.step_raw(a)
+    ex = env.export_boards()
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    order = ("moves", "n_moves", "board", "qmask", "n_q")
+    for first in (0, 1):
+        bufs = {}
+        for k in order:
+            big = torch.zeros((n + 1,) + tuple(ex[k].shape[1:]), dtype=ex[k].dtype, device="cuda")
+            big[first:first + n] = ex[k]
+            bufs[k] = big[first:first + n]
+        other = VecEnv(n, seed=seed)
+        assert L.qttt_import(other.state.data_ptr(), *[bufs[k].data_ptr() for k in order], n, s) == 0
+        back = other.export_boards()
+        for k in order:
+            assert torch.equal(back[k], ex[k]), (first, k)
+        assert torch.equal(other.check_win()[0], env.check_win()[0])
+        ia, ib = other.node_info(), env.node_info()
+        for k in ia:
+            assert torch.equal(ia[k], ib[k]), (first, k)
+        # the imported boards continue like the originals (same seed / step index / ids), attribute for attribute
+        cont = VecEnv.from_state(env.state.clone(), n, seed=seed)
+        cont.step_idx = other.step_idx = 50
+        for _ in range(4):
+            act = cont.sample_actions()
+            assert torch.equal(other.sample_actions(), act)
+            r1, t1 = cont.step_raw(act)
+            r2, t2 = other.step_raw(act)
+            assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(t1, t2)
+        e1, e2 = cont.export_boards(), other.export_boards()
+        for k in order:
+            assert torch.equal(e1[k], e2[k]), (first, k, "after steps")
+    junk = VecEnv(n)
+    g = lambda shape, dt: torch.from_numpy(rng.integers(0, 256, size=shape, dtype=np.uint8)).cuda().view(dt)
+    junk.import_boards(g((n, 9, 2), torch.uint8), g((n,), torch.uint8), g((n, 9), torch.int8),
+                       g((n, 4, 2), torch.uint8).view(torch.int16).reshape(n, 4), g((n,), torch.uint8))
+    for _ in range(3):
+        junk.step_raw(junk.sample_actions())
+    jx = junk.export_boards()
+    torch.cuda.synchronize()                                             # garbage in, garbage out — but no fault and no hang
+    assert jx["n_moves"].shape == (n,) and int(jx["n_moves"].max()) <= 15
