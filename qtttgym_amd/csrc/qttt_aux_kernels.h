@@ -376,31 +376,12 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
     for (u32 t = 0; t < 8u; ++t) {
         const u32 pr = (u32)((t < 4u ? m03 : m47) >> (16u * (t & 3u))) & 0xFFFFu;
         const u32 lo = pr & 0xFFu, hi = pr >> 8;
-        if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u) {
-            u32 v4 = hi * 4u, prev4 = (15u - t) * 4u;                    // hi becomes the child end of move t
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {                                // (rolled: 23.0 against 21.3 us per 1 M boards)
-                const u32 tt = (u32)(P >> v4);
-                const u32 ec4 = tt & 0x3Cu;
-                P ^= (u64)((tt ^ prev4) & 0x3Cu) << v4;                  // sq[v] = prev
-                if (ec4 == 0u) break;                                    // v was the root
-                v4 ^= rotr32(Q0, ec4) & 0x3Cu;
-                prev4 = ec4;
-            }
-        }
+        if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u)
+            P = step_reroot(P, Q0, hi * 4u, t * 4u);                     // hi becomes the child end of move t
     }
     u32 P0 = (u32)P, P1 = (u32)(P >> 32) & 0x3Fu;
     P1 |= (n_real << P1_N_SHIFT) | (((u32)(comps >> 32) & 0xFu) << P1_CHI_SHIFT) | (last_x << P1_LX_SHIFT) | (cl << P1_CL_SHIFT);
-    // ---- done = a completed line or nine moves (env.py:51), as the step computes it (qttt_step_core.h)
-    const u32 par4 = P0 & 0x44444444u;
-    const u32 even4 = __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
-                      (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 << 8) & 0x400u);
-    const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;
-    const u32 pc = (u32)__builtin_popcount(cl4);
-    const u32 O4 = cl4 & ~even4;
-    const u32 X4 = pc >= 8u ? (O4 ^ 0x7FCu) : (cl4 & even4);
-    const u32 win = (u32)lut[X4] | (u32)lut[O4];
-    P1 |= ((win | (pc & 8u)) << 28) & P1_DONE;
+    step_line(P0, P1, lut);                                              // done = a completed line or nine moves (env.py:51)
     Pout = (u64)P0 | ((u64)P1 << 32);
     Qout = (u64)Q0 | ((u64)(u32)comps << 32);
 }

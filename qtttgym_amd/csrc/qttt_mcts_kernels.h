@@ -107,19 +107,14 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(
     if (i >= n) return;
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
     const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
+    // both children in one pass: validity, components, append, qstructs and classical update are shared, only the
+    // path reversal and the line test run per child (step_core_both)
+    u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b;
+    const u32 kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b);   // mcts.py:245
     u64 kidP[2], kidQ[2];
-#pragma unroll
-    for (u32 bit = 0; bit < 2; ++bit) {
-        u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
-        step_core<false>(P0, P1, Q0, Q1, act, bit, lut);
-        kidP[bit] = (u64)P0 | ((u64)P1 << 32);
-        kidQ[bit] = (u64)Q0 | ((u64)Q1 << 32);
-    }
-    const u32 n_before = ((u32)(P >> 32) >> P1_N_SHIFT) & 0xFu;
-    const u32 n_after = ((u32)(kidP[0] >> 32) >> P1_N_SHIFT) & 0xFu;
-    const u32 cl_before = ((u32)(P >> 32) >> P1_CL_SHIFT) & 0x1FFu;
-    const u32 cl_after = ((u32)(kidP[0] >> 32) >> P1_CL_SHIFT) & 0x1FFu;
-    const u32 kids = n_after == n_before ? 0u : (cl_after != cl_before ? 2u : 1u);   // mcts.py:245
+    kidP[0] = (u64)P0a | ((u64)P1a << 32);
+    kidP[1] = (u64)P0b | ((u64)P1b << 32);
+    kidQ[0] = kidQ[1] = (u64)Q0 | ((u64)Q1 << 32);
     n_children[i] = (uint8_t)kids;
     store_stream(&c0P[i], kidP[0]); store_stream(&c0Q[i], kidQ[0]);
     store_stream(&c1P[i], kidP[1]); store_stream(&c1Q[i], kidQ[1]);

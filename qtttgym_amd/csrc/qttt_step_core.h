@@ -6,97 +6,108 @@
 namespace {
 
 // ====================================================================== the hot path
-// One Env.step (env.py:34-53) on the board held in (P0,P1,Q0,Q1).  `lut` is the workgroup's LDS
-// line table (fill_line_lut: one entry per dword, 0x7F = the mask holds a line).  Returns 0x7F iff a
-// completed line exists afterwards (else 0); P1's done bit is updated.
-// TRUSTED: the caller guarantees a legal action with action[0] < action[1] (the in-kernel policy of the
-// rollout does): no sorting, no validation.
-template <bool AUTO_RESET, bool TRUSTED = false>
-__device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 act, u32 bit,
-                                         const uint8_t *lut) {
-    if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
-        const u32 keep = ~(u32)((int)P1 >> 31);         // 0 iff done
-        P0 &= keep;
-        P1 &= keep;
-        Q0 &= keep;
-        Q1 &= keep;
-    }
+// One Env.step (env.py:34-53) on the board held in (P0,P1,Q0,Q1), in four pieces so that qttt_expand can share
+// everything that does not depend on the collapse bit between its two children (all forceinline: step_core below
+// compiles to the code it was as one function):
+//   step_prep     validity (board.py:10-18) + the components of lo / hi, cycle test (board.py:28-42)
+//   step_reroot   the path reversal: re-root x's tree at x, x receives the move as its parent edge
+//   step_fields   append, n += 1, qstructs insert / union / pop in list order, classical |= component (board.py:19,42-69)
+//   step_line     "does any line exist" + done bit (board.py:71-115 reduced to what env.py:49,51 need)
+struct StepPrep {
+    u32 lo, hi, x16, pm, n4, mlo, mhi;
+    u64 comps;
+    bool legal, has_lo, cyc;
+};
+
+template <bool TRUSTED>
+__device__ __forceinline__ StepPrep step_prep(u32 P1, u32 Q1, u32 act) {
+    StepPrep s;
     const u32 a = act & 0xFFu, b = act >> 8;            // action[0], action[1] (env.py:37-38)
-    const u32 lo = TRUSTED ? a : min(a, b), hi = TRUSTED ? b : max(a, b);   // board.py:16-18
+    s.lo = TRUSTED ? a : min(a, b);                     // board.py:16-18
+    s.hi = TRUSTED ? b : max(a, b);
+    s.x16 = (a ^ b) << 16;
     // the two squares as a mask at the classical mask's place in P1 (only looked at when hi < 9)
-    const u32 pmS = ((1u << P1_CL_SHIFT) << (lo & 31u)) | ((1u << P1_CL_SHIFT) << (hi & 31u));
+    const u32 pmS = ((1u << P1_CL_SHIFT) << (s.lo & 31u)) | ((1u << P1_CL_SHIFT) << (s.hi & 31u));
     // board.py:10-15 (+ IndexError for >8, swallowed at env.py:41): reject before mutating
-    if (TRUSTED || (hi < 9u && lo != hi && (P1 & pmS) == 0u)) {
-        const u32 pm = pmS >> P1_CL_SHIFT;
-        const u32 n4 = (P1 >> (P1_N_SHIFT - 2u)) & 0x3Cu;            // 4 * moves played (bits 6,7 of P1 are 0)
-        u64 comps = (u64)Q1 | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
-        const u32 mlo = (u32)(comps >> lo) & SLOT_LSB;   // slot holding lo (board.py:28-33)
-        const u32 mhi = (u32)(comps >> hi) & SLOT_LSB;   // slot holding hi (board.py:35-40)
-        const bool has_lo = mlo != 0u;
-        const bool cyc = (mlo & mhi) != 0u;              // board.py:42: same component -> cycle
-        // x: the square that becomes the child end of the new edge (its tree is re-rooted at it).
-        // On a cycle it is the square the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi);
-        // otherwise either end will do, and an isolated square is the cheap one: hi, unless only lo
-        // is isolated (no walk at all instead of a walk up hi's tree)
-        const u32 x4 = (((cyc && bit == 0u) || (!has_lo && mhi != 0u)) ? lo : hi) * 4u;
-        u64 P = (u64)P0 | ((u64)P1 << 32);
-        {   // re-root x's tree at x: reverse the parent edges along the path x -> old root.
-            // All quantities are "times four": v4 = 4v is the shift that brings square v's nibble
-            // to bits 2..5, ec4 = 4 * code of the edge found there, and rotating Q0 right by ec4
-            // brings 4 * (lo^hi) of that edge to bits 2..5: the other end of the edge is one
-            // rotate and one xor-and away.
-            // x itself receives this move as its parent edge (code of round n), every later node
-            // on the path receives the edge its child used to have.
-            u32 v4 = x4, prev4 = n4 ^ 0x3Cu;
+    s.legal = TRUSTED || (s.hi < 9u && s.lo != s.hi && (P1 & pmS) == 0u);
+    s.pm = pmS >> P1_CL_SHIFT;
+    s.n4 = (P1 >> (P1_N_SHIFT - 2u)) & 0x3Cu;            // 4 * moves played (bits 6,7 of P1 are 0)
+    s.comps = (u64)Q1 | ((u64)((P1 >> P1_CHI_SHIFT) & 0xFu) << 32);
+    s.mlo = (u32)(s.comps >> s.lo) & SLOT_LSB;           // slot holding lo (board.py:28-33)
+    s.mhi = (u32)(s.comps >> s.hi) & SLOT_LSB;           // slot holding hi (board.py:35-40)
+    s.has_lo = s.mlo != 0u;
+    s.cyc = (s.mlo & s.mhi) != 0u;                       // board.py:42: same component -> cycle
+    return s;
+}
+
+// x: the square that becomes the child end of the new edge (its tree is re-rooted at it).  On a cycle it is the
+// square the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi); otherwise either end will do, and an
+// isolated square is the cheap one: hi, unless only lo is isolated (no walk at all instead of a walk up hi's tree)
+__device__ __forceinline__ u32 step_child_end4(const StepPrep &s, u32 bit) {
+    return (((s.cyc && bit == 0u) || (!s.has_lo && s.mhi != 0u)) ? s.lo : s.hi) * 4u;
+}
+
+// re-root x's tree at x: reverse the parent edges along the path x -> old root.  All quantities are "times four":
+// v4 = 4v is the shift that brings square v's nibble to bits 2..5, ec4 = 4 * code of the edge found there, and
+// rotating Q0 right by ec4 brings 4 * (lo^hi) of that edge to bits 2..5: the other end of the edge is one rotate
+// and one xor-and away.  x itself receives this move as its parent edge (code of round n), every later node on
+// the path receives the edge its child used to have.
+__device__ __forceinline__ u64 step_reroot(u64 P, u32 Q0, u32 x4, u32 n4) {
+    u32 v4 = x4, prev4 = n4 ^ 0x3Cu;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const u32 t = (u32)(P >> v4);
-                const u32 ec4 = t & 0x3Cu;
-                P ^= (u64)((t ^ prev4) & 0x3Cu) << v4;   // sq[v] = prev
-                if (ec4 == 0u) break;                    // v was the root
-                v4 ^= rotr32(Q0, ec4) & 0x3Cu;
-                prev4 = ec4;
-            }
-        }
-        P0 = (u32)P;
-        P1 = (u32)(P >> 32);
-        // board.py:19: append.  Only x = lo^hi is kept (see the header): round n <= 7 goes to its
-        // nibble of Q0 (x*4 rotated right by 4n+4, i.e. x<<16 rotated by 4n+18), every move to the
-        // `last x` field; n += 1.
-        const u32 x16 = (a ^ b) << 16;
-        Q0 ^= rotr32(x16, (P1 >> (P1_N_SHIFT - 2u)) + 18u);            // a rotate only looks at the low five bits
-        P1 = ((P1 & ~(0xFu << P1_LX_SHIFT)) | x16) + (1u << P1_N_SHIFT);
-        // ---- board.py:42-69 on the cached qstructs, all cases in one straight line ----
-        // ffbl_raw(0) = -1, a 64-bit shift by -1 (= 63) gives 0: c1 = component of hi, 0 if none
-        const u32 c1 = (u32)(comps >> (ffbl_raw(mhi) & 63u)) & 0x1FFu;
-        // the slot the move goes to (board.py:58-69): lo's, else hi's, else the first empty one.
-        // Slots are compact, so the first empty slot's bit lies above every occupied slot's and a
-        // single "lowest set bit" picks the right one: nz = non-empty flags of slots 0..2 (bits
-        // 8,17,26), t = the LSBs of slots 0..count, t & ~(t >> 9) = the LSB of slot `count`.
-        const u32 tsel = has_lo ? mlo : mhi;
-        const u32 c32 = (u32)comps;
-        const u32 nz = (((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u;
-        const u32 t = (nz << 1) | 1u;
-        const u32 sT = ffbl_raw(tsel | (t & ~(t >> 9)));
-        // the move's squares join the slot; so does hi's component (a no-op unless this is a
-        // union, board.py:58-61: on a cycle or when only hi is in a slot it is that slot already)
-        comps |= (u64)(pm | c1) << sT;
-        // pop hi's slot on a cycle (board.py:56) or a union (board.py:61) <=> both are in a slot
-        const u32 mpop = has_lo ? mhi : 0u;
-        const u32 low = mpop - 1u;                                      // all ones = keep everything
-        const u32 chi2 = (u32)(comps >> 32);
-        Q1 = ((u32)comps & low) | (__builtin_amdgcn_alignbit(chi2, (u32)comps, 9u) & ~low);
-        // after a pop at most three slots are left: bits 27..35 are empty
-        P1 = (P1 & ~(0xFu << P1_CHI_SHIFT)) | ((mpop ? 0u : chi2) << P1_CHI_SHIFT);
-        // board.py:44-56 + qeval.py:5-51: on a cycle every square of the component goes classical
-        // and already holds its parent edge's round; x holds the closing move's round
-        P1 |= (cyc ? c1 : 0u) << P1_CL_SHIFT;
+    for (int i = 0; i < 9; ++i) {
+        const u32 t = (u32)(P >> v4);
+        const u32 ec4 = t & 0x3Cu;
+        P ^= (u64)((t ^ prev4) & 0x3Cu) << v4;   // sq[v] = prev
+        if (ec4 == 0u) break;                    // v was the root
+        v4 ^= rotr32(Q0, ec4) & 0x3Cu;
+        prev4 = ec4;
     }
-    // board.py:71-115 reduced to "does any line exist" (all that env.py:49,51 need): parity of the
-    // round on each classical square -> X / O masks -> table lookup.  Codes are complemented, so
-    // a set low bit means an EVEN round (X).  All masks here are "times four" (bit v+2 = square v).
-    // Eight classical squares = the autofill of board.py:22-25 is due: the ninth square counts as
-    // X (round 8) — with 8 or 9 classical squares X is simply "everything that is not O".
+    return P;
+}
+
+// everything of the move that does not depend on the collapse bit; P1 holds the fields (its nibble bits pass through)
+__device__ __forceinline__ void step_fields(const StepPrep &s, u32 &P1, u32 &Q0, u32 &Q1) {
+    u64 comps = s.comps;
+    // board.py:19: append.  Only x = lo^hi is kept (see the header): round n <= 7 goes to its
+    // nibble of Q0 (x*4 rotated right by 4n+4, i.e. x<<16 rotated by 4n+18), every move to the
+    // `last x` field; n += 1.
+    Q0 ^= rotr32(s.x16, (P1 >> (P1_N_SHIFT - 2u)) + 18u);            // a rotate only looks at the low five bits
+    P1 = ((P1 & ~(0xFu << P1_LX_SHIFT)) | s.x16) + (1u << P1_N_SHIFT);
+    // ---- board.py:42-69 on the cached qstructs, all cases in one straight line ----
+    // ffbl_raw(0) = -1, a 64-bit shift by -1 (= 63) gives 0: c1 = component of hi, 0 if none
+    const u32 c1 = (u32)(comps >> (ffbl_raw(s.mhi) & 63u)) & 0x1FFu;
+    // the slot the move goes to (board.py:58-69): lo's, else hi's, else the first empty one.
+    // Slots are compact, so the first empty slot's bit lies above every occupied slot's and a
+    // single "lowest set bit" picks the right one: nz = non-empty flags of slots 0..2 (bits
+    // 8,17,26), t = the LSBs of slots 0..count, t & ~(t >> 9) = the LSB of slot `count`.
+    const u32 tsel = s.has_lo ? s.mlo : s.mhi;
+    const u32 c32 = (u32)comps;
+    const u32 nz = (((c32 & 0x03FDFEFFu) + 0x03FDFEFFu) | c32) & 0x04020100u;
+    const u32 t = (nz << 1) | 1u;
+    const u32 sT = ffbl_raw(tsel | (t & ~(t >> 9)));
+    // the move's squares join the slot; so does hi's component (a no-op unless this is a
+    // union, board.py:58-61: on a cycle or when only hi is in a slot it is that slot already)
+    comps |= (u64)(s.pm | c1) << sT;
+    // pop hi's slot on a cycle (board.py:56) or a union (board.py:61) <=> both are in a slot
+    const u32 mpop = s.has_lo ? s.mhi : 0u;
+    const u32 low = mpop - 1u;                                      // all ones = keep everything
+    const u32 chi2 = (u32)(comps >> 32);
+    Q1 = ((u32)comps & low) | (__builtin_amdgcn_alignbit(chi2, (u32)comps, 9u) & ~low);
+    // after a pop at most three slots are left: bits 27..35 are empty
+    P1 = (P1 & ~(0xFu << P1_CHI_SHIFT)) | ((mpop ? 0u : chi2) << P1_CHI_SHIFT);
+    // board.py:44-56 + qeval.py:5-51: on a cycle every square of the component goes classical
+    // and already holds its parent edge's round; x holds the closing move's round
+    P1 |= (s.cyc ? c1 : 0u) << P1_CL_SHIFT;
+}
+
+// board.py:71-115 reduced to "does any line exist" (all that env.py:49,51 need): parity of the
+// round on each classical square -> X / O masks -> table lookup.  Codes are complemented, so
+// a set low bit means an EVEN round (X).  All masks here are "times four" (bit v+2 = square v).
+// Eight classical squares = the autofill of board.py:22-25 is due: the ninth square counts as
+// X (round 8) — with 8 or 9 classical squares X is simply "everything that is not O".
+// Returns 0x7F iff a completed line exists (else 0); P1's done bit is updated.
+__device__ __forceinline__ u32 step_line(u32 P0, u32 &P1, const uint8_t *lut) {
     const u32 par4 = P0 & 0x44444444u;
     const u32 even4 = __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
                       (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 << 8) & 0x400u);
@@ -109,6 +120,55 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
     // pc <= 9: bit 3 of (win | pc & 8) is the answer
     P1 = (P1 & ~P1_DONE) | (((win | (pc & 8u)) << 28) & P1_DONE);
     return win;
+}
+
+// `lut` is the workgroup's LDS line table (fill_line_lut: one entry per dword, 0x7F = the mask holds a line).
+// Returns 0x7F iff a completed line exists afterwards (else 0); P1's done bit is updated.
+// TRUSTED: the caller guarantees a legal action with action[0] < action[1] (the in-kernel policy of the
+// rollout does): no sorting, no validation.
+template <bool AUTO_RESET, bool TRUSTED = false>
+__device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 act, u32 bit,
+                                         const uint8_t *lut) {
+    if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
+        const u32 keep = ~(u32)((int)P1 >> 31);         // 0 iff done
+        P0 &= keep;
+        P1 &= keep;
+        Q0 &= keep;
+        Q1 &= keep;
+    }
+    const StepPrep s = step_prep<TRUSTED>(P1, Q1, act);
+    if (s.legal) {
+        const u64 P = step_reroot((u64)P0 | ((u64)P1 << 32), Q0, step_child_end4(s, bit), s.n4);
+        P0 = (u32)P;
+        P1 = (u32)(P >> 32);
+        step_fields(s, P1, Q0, Q1);
+    }
+    return step_line(P0, P1, lut);
+}
+
+// Both values of the collapse bit at once (MCTS._step, mcts.py:233-267): child a = the closing move on lo (bit 0),
+// child b = on hi (bit 1).  Everything but the path reversal and the line test is shared; without a cycle the
+// children are the same board.  Returns n_children: 0 = make_move raises, 1 = no collapse, 2 = collapse.
+__device__ __forceinline__ u32 step_core_both(u32 P0, u32 P1, u32 &Q0, u32 &Q1, u32 act, const uint8_t *lut,
+                                              u32 &P0a, u32 &P1a, u32 &P0b, u32 &P1b) {
+    const StepPrep s = step_prep<false>(P1, Q1, act);
+    P0a = P0b = P0;
+    P1a = P1b = P1;
+    if (s.legal) {
+        const u64 P = (u64)P0 | ((u64)P1 << 32);
+        const u64 Pa = step_reroot(P, Q0, step_child_end4(s, 0u), s.n4);
+        const u64 Pb = s.cyc ? step_reroot(P, Q0, step_child_end4(s, 1u), s.n4) : Pa;
+        u32 F = P1;                                      // the fields are the same for both children
+        step_fields(s, F, Q0, Q1);
+        F &= ~0x3Fu;
+        P0a = (u32)Pa;
+        P1a = F | ((u32)(Pa >> 32) & 0x3Fu);
+        P0b = (u32)Pb;
+        P1b = F | ((u32)(Pb >> 32) & 0x3Fu);
+    }
+    step_line(P0a, P1a, lut);
+    step_line(P0b, P1b, lut);
+    return s.legal ? (s.cyc ? 2u : 1u) : 0u;
 }
 
 // classical mask the policy sees (a finished board counts as empty under auto-reset)
