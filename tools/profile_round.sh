@@ -7,6 +7,7 @@
 #   kt_full   the same over the DEFAULT command with its legs (what the driver runs), --stats table only
 #   kt16      16 777 216 boards per launch (a 105 us kernel: the profiler's per-dispatch cost no longer shows)
 #   kt_gym    --mode gym;  kt_fused  --mode random-fused at 262 144 boards (BASELINE config 3 / config 4's shard)
+#   kt_rows   tools/bench_rows.py: the kernels beside the step (observe, export, import, node_info, expand, rollout, ...)
 #   pmc_f / pmc_w   FETCH_SIZE / WRITE_SIZE at 1 048 576 boards; pmc_f16 / pmc_w16 at 16 777 216
 #   pmc_sq, pmc_sq_fused, pmc_sq_rows   SQ instruction / cycle counters: replay, random-fused, tools/bench_rows.py
 # The program after `--` is python3 itself (no env/bash hop: the profiler's preload has touched the GPU).
@@ -23,6 +24,7 @@ run kt       rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt"  
 run kt_full  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_full"  -- python3 "$B" --no-cpu-baseline "$@"
 run kt16     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt16"     -- python3 "$B" --boards 16777216 --steps 10 --warmup 2 --regions 4 $N "$@"
 run kt_gym   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_gym"   -- python3 "$B" --steps 20 --warmup 5 $N --mode gym "$@"
+run kt_rows  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_rows"  -- python3 "$R/tools/bench_rows.py"
 run kt_fused rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_fused" -- python3 "$B" --boards 262144 --steps 128 --warmup 10 --regions 20 $N --mode random-fused "$@"
 run pmc_f    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_f"   -- python3 "$B" --steps 20 --warmup 5 --regions 3 $N "$@"
 run pmc_w    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_w"   -- python3 "$B" --steps 20 --warmup 5 --regions 3 $N "$@"
