@@ -21,7 +21,7 @@ cp "$P"/kt_full/runc/*_kernel_stats.csv "$O/kernel_stats_default_command_with_le
 cp "$P"/kt16/runc/*_kernel_stats.csv "$O/kernel_stats_16M_boards.csv"
 cp "$P"/kt_gym/runc/*_kernel_stats.csv "$O/kernel_stats_gym.csv"
 cp "$P"/kt_fused/runc/*_kernel_stats.csv "$O/kernel_stats_random_fused_262144.csv"
-[ -d "$P/kt_rows" ] && cp "$P"/kt_rows/runc/*_kernel_stats.csv "$O/kernel_stats_rows.csv"
+[ -d "$P/kt_rows" ] && python3 tools/trace_rows_summary.py "$P/kt_rows" > "$O/kernel_trace_rows.csv"
 for n in kt kt_full kt16 kt_gym kt_fused; do grep "^{" "$P/$n.log" > "$O/bench_${n}_under_rocprof.json"; done
 python3 tools/pmc_summary.py 1048576 "$P/pmc_f" "$P/pmc_w" "$(basename "$O") step_kernel<1024,2,false,true,false,false> via bench.py --steps 20 --warmup 5 --regions 3 --no-legs" 16 > /dev/null
 python3 tools/pmc_summary.py 16777216 "$P/pmc_f16" "$P/pmc_w16" "$(basename "$O") step_kernel<256,2,false,true,false,false> via bench.py --boards 16777216 --steps 10 --warmup 2 --regions 2 --no-legs" 16 > /dev/null
