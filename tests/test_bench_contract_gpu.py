@@ -112,8 +112,11 @@ def test_bench_default_line_carries_the_legs():
     assert legs["beyond_infinity_cache_16777216_boards"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7
     assert 16777216 * (2 * sb) > 256 << 20                                     # the state alone exceeds the Infinity Cache
     assert legs["gym_1048576_boards"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7 + 30
+    c5 = legs["config5_expand_node_info_rollout_65536_boards"]
+    assert c5["us_per_unit_with_10_playouts_per_leaf"] < c5["us_per_unit"] + 9 * 9.0      # ten playouts per leaf: one launch, not ten
     f = legs["random_fused_262144_boards"]
     assert f["bound"] == "valu" and f["steps_per_launch"] == 64 and f["us_per_step"] < legs["config3_262144_boards"]["us_per_step"]
+    assert 0.3 < f["issue_frac"] < 1.0 and 0.5 < legs["random_fused_1048576_boards"]["issue_frac"] < 1.05
 
 
 def test_bench_total_boards_is_strong_scaling():
