@@ -96,10 +96,13 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
  * (with QTTT_FLAG_AUTO_RESET a finished board restarts on its next ply).  Bit-identical to n_steps calls
  * of qttt_step_random.  Step t writes actions_out + 2*t*out_stride, reward + t*out_stride and
  * terminated + t*out_stride (out_stride in boards; 0: only the last step's outputs are written, to the
- * first n elements).  actions_out is nullable; reward and terminated are nullable together. */
+ * first n elements).  actions_out is nullable; reward and terminated are nullable together.
+ *   returns f32[n], nullable: ACCUMULATED, returns[i] += the sum of board i's n_steps rewards (each -1.0 or -0.0,
+ *   env.py:49) — with auto-reset minus the number of its plies that ended with a completed line: the per-board
+ *   episode returns a multi-GPU caller gathers without keeping any per-ply output. */
 int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
                           uint32_t flags, uint8_t *actions_out, float *reward, uint8_t *terminated,
-                          int64_t out_stride, int64_t n, int32_t n_steps, void *stream);
+                          int64_t out_stride, float *returns, int64_t n, int32_t n_steps, void *stream);
 
 /* Env._observation (env.py:68-85) for n boards.
  *   classical i8[n,9]   Board.board (-1 empty else round)

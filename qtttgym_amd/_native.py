@@ -36,7 +36,7 @@ SIGNATURES = {
     "qttt_step_observe": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i64, _vp]),
     "qttt_step_many": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _i64, _i32, _vp]),
-    "qttt_step_random_many": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "qttt_step_random_many": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "qttt_observe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_check_win": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qttt_export": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

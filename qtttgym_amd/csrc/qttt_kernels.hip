@@ -353,11 +353,11 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
 
 int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset, uint32_t flags,
                           uint8_t *actions_out, float *reward, uint8_t *terminated, int64_t out_stride,
-                          int64_t n, int32_t n_steps, void *stream) {
+                          float *returns, int64_t n, int32_t n_steps, void *stream) {
     if (n < 0 || board_offset < 0 || n_steps < 0 || out_stride < 0) return QTTT_ERR_SIZE;
     if (n == 0 || n_steps == 0) return 0;
     if (!state || (reward == nullptr) != (terminated == nullptr)) return QTTT_ERR_NULL;
-    if (((uintptr_t)actions_out & 1u) || ((uintptr_t)reward & 3u)) return QTTT_ERR_ACTION;
+    if (((uintptr_t)actions_out & 1u) || ((uintptr_t)reward & 3u) || ((uintptr_t)returns & 3u)) return QTTT_ERR_ACTION;
     Planes p = planes(state, n);
     hipStream_t s = (hipStream_t)stream;
     uint16_t *a16 = reinterpret_cast<uint16_t *>(actions_out);
@@ -365,10 +365,11 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
     // 256-thread workgroups: the finest spread of a small batch over the 256 CUs (4 096 boards = 16 CUs
     // with 512 threads, 16 with 256 — but 262 144 boards = 1 024 workgroups, four per CU, instead of two)
-#define QTTT_RF(AR) hipLaunchKernelGGL((step_random_fused_kernel<256, AR>), dim3(blocks_for(n, 256)), dim3(256), 0, s, \
-                                       p.P, p.Q, (u64)seed, step_idx0, (u64)board_offset, a16, rb, terminated,        \
-                                       out_stride, n, n_steps)
-    if (ar) QTTT_RF(true); else QTTT_RF(false);
+#define QTTT_RF(AR, RT) hipLaunchKernelGGL((step_random_fused_kernel<256, AR, RT>), dim3(blocks_for(n, 256)), dim3(256), 0, s, \
+                                           p.P, p.Q, (u64)seed, step_idx0, (u64)board_offset, a16, rb, terminated,    \
+                                           out_stride, n, n_steps, returns)
+    if (returns) { if (ar) QTTT_RF(true, true); else QTTT_RF(false, true); }
+    else         { if (ar) QTTT_RF(true, false); else QTTT_RF(false, false); }
 #undef QTTT_RF
     return launch_status();
 }

@@ -194,11 +194,11 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
 //   nth9 / policy_action_nth9: qttt_state.h (the full 4.5 KB "r-th empty square" table, computed by the workgroup).
 // With AUTO_RESET the policy always has a legal pair (a board that is not done has >= 2 empty squares:
 // 8 classical squares set the done bit), so the step runs TRUSTED (no validation, no sorting).
-template <int BLOCK, bool AUTO_RESET>
+template <int BLOCK, bool AUTO_RESET, bool RETURNS = false>
 __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, u64 seed, u32 step_idx0, u64 board_offset,
     uint16_t *__restrict__ actions_out, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
-    int64_t out_stride, int64_t n, int32_t n_steps) {
+    int64_t out_stride, int64_t n, int32_t n_steps, float *__restrict__ returns) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
     __shared__ uint8_t nth9[512 * 9];
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     u32 *r_blk = reward_bits ? reward_bits + ib : nullptr;
     uint8_t *t_blk = terminated ? terminated + ib : nullptr;
     const u32 lane = threadIdx.x;
+    u32 lines = 0;                                                  // plies whose reward was -1.0 (env.py:49): -(the return)
     for (int32_t t = 0; t < n_steps; ++t) {
         const u64 key = launch_key(seed, step_idx0 + (u32)t);       // wave-uniform: scalar unit
         const u32 h1 = lowbias32(id ^ (u32)key);
@@ -243,9 +244,11 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
                 store_stream(&t_blk[lane], (uint8_t)(P1 >> 31));              // env.py:51
             }
         }
+        if (RETURNS) lines += win & 1u;                             // (its own instantiation: the ordinary ply carries nothing extra)
         if (a_blk) a_blk += out_stride;
         if (r_blk) { r_blk += out_stride; t_blk += out_stride; }
     }
+    if (RETURNS) returns[i] -= (float)lines;                        // the sum of the rewards of these plies, accumulated
     store_stream(&pP[i], (u64)P0 | ((u64)P1 << 32));
     store_stream(&pQ[i], (u64)Q0 | ((u64)Q1 << 32));
 }

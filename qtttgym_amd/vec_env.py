@@ -390,12 +390,13 @@ class VecEnv:
         _native.check(rc, "qttt_sample_actions")
         return out
 
-    def step_random_many(self, n_steps, actions_out=None, reward=None, terminated=None):
+    def step_random_many(self, n_steps, actions_out=None, reward=None, terminated=None, returns=None):
         """n_steps steps under the in-kernel uniform-legal policy in ONE launch with the boards in
         registers (qttt_step_random_many) == n_steps calls of step_random().  With reward f32[T,N] +
         terminated bool[T,N] (and optionally actions_out u8[T,N,2]) every step's outputs are kept; without
         them only the last step's are written (to the environment's own reward / terminated buffers, which
-        are returned; actions_out u8[N,2] optional)."""
+        are returned; actions_out u8[N,2] optional).  returns f32[N] (optional) is ACCUMULATED: += the sum of each
+        board's rewards over these plies (env.py:49) — the per-board episode returns, with no per-ply output kept."""
         n, T, dev = self.num_envs, int(n_steps), self.state.device
         keep = reward is not None or terminated is not None
         stride = 0
@@ -407,9 +408,11 @@ class VecEnv:
             stride = n
         if actions_out is not None:        # one out_stride for all outputs: [T,N,2] with reward/terminated [T,N], else [N,2]
             _check_out(actions_out, torch.uint8, (T, n, 2) if keep else (n, 2), dev, "actions_out")
+        if returns is not None:
+            _check_out(returns, torch.float32, (n,), dev, "returns")
         rc = self._launch(self._lib.qttt_step_random_many, self.state.data_ptr(), self.seed, self.step_idx,
-                          self.board_offset, self._flags(), _ptr(actions_out), r.data_ptr(), tm.data_ptr(), stride, n, T,
-                          self._stream())
+                          self.board_offset, self._flags(), _ptr(actions_out), r.data_ptr(), tm.data_ptr(), stride,
+                          _ptr(returns), n, T, self._stream())
         _native.check(rc, "qttt_step_random_many")
         self._advance(T)
         return r, tm

@@ -58,9 +58,9 @@ def test_env_record_call_validates_before_touching_the_device():
     assert L.qttt_env_step(ctypes.byref(rec), None, None, 0, _native.ENV_STEP_OBSERVE, None) == -1     # no observation buffers
     assert L.qttt_counter_add(None, 1, None) == -1
     # the fused random stepper and the nullable-output entries: argument errors, no device work
-    assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, 8, 4, None) == -1
-    assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, -1, 4, None) == -2
-    assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, 8, 0, None) == 0             # no steps: nothing to do
+    assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, None, 8, 4, None) == -1
+    assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, None, -1, 4, None) == -2
+    assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, None, 8, 0, None) == 0             # no steps: nothing to do
     assert L.qttt_export(None, None, None, None, None, None, 8, None) == -1
     assert L.qttt_node_info(None, None, None, None, None, 8, None) == -1
     assert L.qttt_export(None, None, None, None, None, None, 0, None) == 0

@@ -108,14 +108,14 @@ def test_step_random_many_argument_errors():
     r = torch.empty(n, dtype=torch.float32, device="cuda")
     tm = torch.empty(n, dtype=torch.bool, device="cuda")
     st = env.state.data_ptr()
-    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, n, 0, s) == 0      # no steps
-    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, 0, 5, s) == 0      # no boards
-    assert L.qttt_step_random_many(None, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, n, 5, s) == -1
-    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), None, 0, n, 5, s) == -1              # reward without terminated
-    assert L.qttt_step_random_many(st, 1, 0, -1, 0, None, r.data_ptr(), tm.data_ptr(), 0, n, 5, s) == -2
-    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), -1, n, 5, s) == -2
-    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr() + 2, tm.data_ptr(), 0, n, 5, s) == -3
-    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, None, None, 0, n, 5, s) == 0                      # state only
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, None, n, 0, s) == 0      # no steps
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, None, 0, 5, s) == 0      # no boards
+    assert L.qttt_step_random_many(None, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), 0, None, n, 5, s) == -1
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), None, 0, None, n, 5, s) == -1              # reward without terminated
+    assert L.qttt_step_random_many(st, 1, 0, -1, 0, None, r.data_ptr(), tm.data_ptr(), 0, None, n, 5, s) == -2
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr(), tm.data_ptr(), -1, None, n, 5, s) == -2
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, r.data_ptr() + 2, tm.data_ptr(), 0, None, n, 5, s) == -3
+    assert L.qttt_step_random_many(st, 1, 0, 0, 0, None, None, None, 0, None, n, 5, s) == 0                      # state only
     with pytest.raises(ValueError):
         env.step_random_many(3, reward=torch.empty((3, n), dtype=torch.float32, device="cuda"))
     with pytest.raises(ValueError):
@@ -640,3 +640,28 @@ def test_import_tiles_round_trip_misaligned_views_and_garbage(n):
     jx = junk.export_boards()
     torch.cuda.synchronize()                                             # garbage in, garbage out — but no fault and no hang
     assert jx["n_moves"].shape == (n,) and int(jx["n_moves"].max()) <= 15
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_step_random_many_accumulates_per_board_returns(auto_reset):
+    """returns[i] += the sum of board i's rewards over the launch (env.py:49: -1.0 / -0.0 per ply): the per-board
+    episode returns SURVEY §8(e) lets a multi-GPU run gather, produced without keeping a single per-ply output."""
+    from qtttgym_amd import VecEnv
+    n, seed = 50001, 13
+    a = VecEnv(n, seed=seed, auto_reset=auto_reset)
+    b = VecEnv(n, seed=seed, auto_reset=auto_reset)
+    ret = torch.full((n,), 2.0, dtype=torch.float32, device="cuda")     # accumulated onto what is there
+    total = torch.full((n,), 2.0, dtype=torch.float32, device="cuda")
+    for T in (1, 9, 40):
+        a.step_random_many(T, returns=ret)
+        r = torch.empty((T, n), dtype=torch.float32, device="cuda")
+        tm = torch.empty((T, n), dtype=torch.bool, device="cuda")
+        b.step_random_many(T, reward=r, terminated=tm)
+        total += r.sum(dim=0)
+        assert torch.equal(ret, total), T
+        assert torch.equal(a.state, b.state)
+    assert float(ret.min()) < 2.0 - (3.0 if auto_reset else 0.5)
+    with pytest.raises(ValueError):
+        a.step_random_many(3, returns=ret[:-1])
+    L, s = a._lib, torch.cuda.current_stream().cuda_stream
+    assert L.qttt_step_random_many(a.state.data_ptr(), 1, 0, 0, 0, None, None, None, 0, ret.data_ptr() + 2, n, 3, s) == -3

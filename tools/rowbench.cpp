@@ -66,7 +66,7 @@ int main(int argc, char **argv) {
     Planes p = planes(state, n);
     if (plies > 0)
         hipLaunchKernelGGL((step_random_fused_kernel<256, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.P, p.Q,
-                           (u64)7, 0u, (u64)0, (uint16_t *)nullptr, (u32 *)nullptr, (uint8_t *)nullptr, (int64_t)0, n, plies);
+                           (u64)7, 0u, (u64)0, (uint16_t *)nullptr, (u32 *)nullptr, (uint8_t *)nullptr, (int64_t)0, n, plies, (float *)nullptr);
     CK(hipStreamSynchronize(s));
     ExpOut eo;
     CK(hipMalloc(&eo.moves, n * 18)); CK(hipMalloc(&eo.n_moves, n)); CK(hipMalloc(&eo.board, n * 9));
