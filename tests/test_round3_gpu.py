@@ -372,14 +372,14 @@ def _dist_worker(rank, world, port, q):
     assert (env.board_offset, env.board_offset + n) == shard_range(DIST_TOTAL, rank, world)
     r = torch.empty((DIST_T, n), dtype=torch.float32, device="cuda")
     tm = torch.empty((DIST_T, n), dtype=torch.bool, device="cuda")
-    env.step_random_many(DIST_T, reward=r, terminated=tm)
+    ret = torch.zeros(n, dtype=torch.float32, device="cuda")
+    env.step_random_many(DIST_T, reward=r, terminated=tm, returns=ret)    # the kernel's own per-board returns
     counters = EpisodeCounters("cuda")
     for t in range(DIST_T):
         counters.update(r[t], tm[t])
     counters.c = counters.c.cpu()                          # gloo reduces host tensors
     total = counters.all_reduce().clone()
-    returns = r.sum(dim=0).cpu()
-    gathered = gather_returns(returns, dst=0)
+    gathered = gather_returns(ret.cpu(), dst=0)
     q.put((rank, total.tolist(), None if gathered is None else gathered.numpy(), env.turn().cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
