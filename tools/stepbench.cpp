@@ -69,15 +69,24 @@ __global__ __launch_bounds__(256) void floor_kernel(u64 *pA, u64 *pB, u32 *pC, c
 }
 
 // the same with a 16-byte state (planes A and B only): what a 39 B/step layout would reach
-template <int BPL, int BLK = 256>
+// PLAIN_LD: the loads without the non-temporal hint (the stores keep it)
+template <int BPL, int BLK = 256, bool PLAIN_LD = false>
 __global__ __launch_bounds__(BLK) void floor16_kernel(u64 *pA, u64 *pB, const uint16_t *actions,
                                                       u32 *reward, uint8_t *term, int64_t n_groups) {
     int64_t j = (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (j >= n_groups) return;
     int64_t i0 = j * BPL;
-    Vec<u64, BPL> a = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pA + i0));
-    Vec<u64, BPL> b = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pB + i0));
-    Vec<uint16_t, BPL> act = ld_nt(reinterpret_cast<const Vec<uint16_t, BPL> *>(actions + i0));
+    Vec<u64, BPL> a, b;
+    Vec<uint16_t, BPL> act;
+    if (PLAIN_LD) {
+        a = *reinterpret_cast<const Vec<u64, BPL> *>(pA + i0);
+        b = *reinterpret_cast<const Vec<u64, BPL> *>(pB + i0);
+        act = *reinterpret_cast<const Vec<uint16_t, BPL> *>(actions + i0);
+    } else {
+        a = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pA + i0));
+        b = ld_nt(reinterpret_cast<const Vec<u64, BPL> *>(pB + i0));
+        act = ld_nt(reinterpret_cast<const Vec<uint16_t, BPL> *>(actions + i0));
+    }
     Vec<u32, BPL> rw; Vec<uint8_t, BPL> tm;
 #pragma unroll
     for (int k = 0; k < BPL; ++k) {
@@ -152,7 +161,7 @@ int main(int argc, char **argv) {
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     u64 *pA = (u64 *)state; int64_t stride = (n + 63) & ~63ll; u64 *pB = pA + stride; u32 *pC = (u32 *)(pB + stride);
-    std::vector<float> fl[3], fl16, fl16big;
+    std::vector<float> fl[3], fl16, fl16big, fl16plain;
     for (int r = 0; r < reps; ++r) {
         for (size_t li = 0; li < libs.size(); ++li) {
             Lib &L = libs[(li + (size_t)r) % libs.size()];      // rotate the order: the slot after the floor kernels is slower
@@ -212,6 +221,18 @@ int main(int argc, char **argv) {
             CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             fl16big.push_back(ms * 1e3f / K);
+        }
+        {   // and with plain (temporal) loads
+            CK(hipEventRecord(e0, s));
+            for (int t = 0; t < K; ++t) {
+                const uint16_t *a16 = (const uint16_t *)(actions + (size_t)(W + t) * 2 * n);
+                int64_t ng = n / 2; dim3 g((unsigned)((ng + 1023) / 1024)), b(1024);
+                hipLaunchKernelGGL((floor16_kernel<2, 1024, true>), g, b, 0, s, pA, pB, a16, (u32 *)reward, term, ng);
+            }
+            CK(hipEventRecord(e1, s));
+            CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            fl16plain.push_back(ms * 1e3f / K);
         }
     }
     // optional: per-wave timeline of one launch from a -DQTTT_DEBUG_STAMPS build (last lib)
@@ -294,5 +315,8 @@ int main(int argc, char **argv) {
     std::sort(fl16big.begin(), fl16big.end());
     printf("floor 16-byte state, bpl=2, 1024-thread WG %7s us/launch min %6.2f med %6.2f  %19s %5.0f GB/s (39 B/step)\n", "",
            fl16big.front(), fl16big[fl16big.size() / 2], "", 39.0 * n / fl16big.front() * 1e-3);
+    std::sort(fl16plain.begin(), fl16plain.end());
+    printf("floor 16-byte state, bpl=2, 1024-thread WG, plain loads us/launch min %6.2f med %6.2f  %19s %5.0f GB/s (39 B/step)\n",
+           fl16plain.front(), fl16plain[fl16plain.size() / 2], "", 39.0 * n / fl16plain.front() * 1e-3);
     return 0;
 }
