@@ -48,6 +48,67 @@ __global__ __launch_bounds__(BLOCK) void export_floor(const u64 *pP, const u64 *
     }
 }
 
+// EXPERIMENT (measured, not adopted): the fused random stepper with TWO boards per lane (two independent chains in one
+// instruction stream), auto-reset, every ply's outputs kept; even n only.  us per 64-ply launch, one / two boards per
+// lane: 65 536 boards 41.4 / 61.5, 262 144: 80.0 / 86.0, 524 288: 134 / 140, 1 M: 243 / 254 — waves, not chains per
+// wave, are what the SIMDs want
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void step_random_fused2_kernel(
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, u64 seed, u32 step_idx0, u64 board_offset,
+    uint16_t *__restrict__ actions_out, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
+    int64_t out_stride, int64_t n, int32_t n_steps) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    __shared__ uint8_t nth9[512 * 9];
+    typedef Vec<u64, 2> V64;
+    const int64_t jb = (int64_t)blockIdx.x * BLOCK;                 // first lane-group of the workgroup
+    const int64_t j = jb + threadIdx.x;
+    const bool active = 2 * j + 1 < n;
+    const int64_t jl = active ? j : 0;
+    V64 p = load_stream(&reinterpret_cast<const V64 *>(pP)[jl]);
+    V64 q = load_stream(&reinterpret_cast<const V64 *>(pQ)[jl]);
+    fill_policy_lut<BLOCK>(plut);
+    fill_nth9<BLOCK>(nth9);
+    fill_line_lut<BLOCK>(lut);
+    if (!active) return;
+    u32 P0[2], P1[2], Q0[2], Q1[2], id[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        P0[k] = (u32)p.v[k]; P1[k] = (u32)(p.v[k] >> 32); Q0[k] = (u32)q.v[k]; Q1[k] = (u32)(q.v[k] >> 32);
+        id[k] = fold_id(board_offset + (u64)(2 * j + k));
+    }
+    u32 *a_blk = reinterpret_cast<u32 *>(actions_out + 2 * jb);
+    u64 *r_blk = reinterpret_cast<u64 *>(reward_bits + 2 * jb);
+    uint16_t *t_blk = reinterpret_cast<uint16_t *>(terminated + 2 * jb);
+    const u32 lane = threadIdx.x;
+    for (int32_t t = 0; t < n_steps; ++t) {
+        const u64 key = launch_key(seed, step_idx0 + (u32)t);
+        u32 act[2], win[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const u32 h1 = lowbias32(id[k] ^ (u32)key);
+            const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
+            const u32 keep = ~(u32)((int)P1[k] >> 31);
+            P0[k] &= keep; P1[k] &= keep; Q0[k] &= keep; Q1[k] &= keep;
+            const u32 empty = ~(P1[k] >> P1_CL_SHIFT) & 0x1FFu;
+            act[k] = policy_action_nth9(plut, nth9, empty, h2);
+            win[k] = step_core<false, true>(P0[k], P1[k], Q0[k], Q1[k], act[k], h1 >> 31, lut);
+        }
+        store_stream(&a_blk[lane], act[0] | (act[1] << 16));
+        const u64 rw = (u64)(0x80000000u | (win[0] << 23)) | ((u64)(0x80000000u | (win[1] << 23)) << 32);
+        store_stream(&r_blk[lane], rw);
+        store_stream(&t_blk[lane], (uint16_t)((P1[0] >> 31) | ((P1[1] >> 31) << 8)));
+        a_blk += out_stride / 2 * 1;                                  // strides in boards: two boards per element
+        r_blk += out_stride / 2;
+        t_blk += out_stride / 2;
+    }
+    V64 po, qo;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { po.v[k] = (u64)P0[k] | ((u64)P1[k] << 32); qo.v[k] = (u64)Q0[k] | ((u64)Q1[k] << 32); }
+    store_stream(&reinterpret_cast<V64 *>(pP)[j], po);
+    store_stream(&reinterpret_cast<V64 *>(pQ)[j], qo);
+}
+
 struct Variant {
     std::string name;
     std::function<void(hipStream_t)> launch;
@@ -107,17 +168,33 @@ int main(int argc, char **argv) {
     ExpOut only_n = {nullptr, eo.n_moves, nullptr, nullptr, nullptr};
     vs.push_back({"export<256,1> n_moves only (turn)", [=](hipStream_t st) {
         hipLaunchKernelGGL((export_kernel<256, 1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.P, p.Q, only_n, n); }, {}});
+    // fused random stepping, one against two boards per lane: T = 64 plies per launch, every ply's outputs kept
+    {
+        u64 *st2; CK(hipMalloc(&st2, s64 * 16)); CK(hipMemset(st2, 0, s64 * 16));
+        Planes q2 = planes(st2, n);
+        uint16_t *fa; u32 *fr; uint8_t *ft;
+        CK(hipMalloc(&fa, (size_t)64 * n * 2)); CK(hipMalloc(&fr, (size_t)64 * n * 4)); CK(hipMalloc(&ft, (size_t)64 * n));
+        vs.push_back({"random_fused 1 board/lane <256>, 64 plies (us per LAUNCH)", [=](hipStream_t st) {
+            hipLaunchKernelGGL((step_random_fused_kernel<256, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               q2.P, q2.Q, (u64)3, 0u, (u64)0, fa, fr, ft, (int64_t)n, n, 64, (float *)nullptr); }, {}});
+#define RF2(BLK)                                                                                                        \
+        vs.push_back({"random_fused 2 boards/lane <" #BLK ">, 64 plies (us per LAUNCH)", [=](hipStream_t st) {          \
+            hipLaunchKernelGGL((step_random_fused2_kernel<BLK>), dim3((unsigned)((n / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st, \
+                               q2.P, q2.Q, (u64)3, 0u, (u64)0, fa, fr, ft, (int64_t)n, n, 64); }, {}});
+        RF2(128) RF2(256) RF2(512)
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int r = 0; r < reps; ++r)
         for (size_t i = 0; i < vs.size(); ++i) {
             Variant &v = vs[(i + r) % vs.size()];
+            const int Kv = v.name.rfind("random_fused", 0) == 0 ? std::max(1, K / 10) : K;   // a 64-ply launch is long
             for (int k = 0; k < 3; ++k) v.launch(s);
             CK(hipEventRecord(e0, s));
-            for (int k = 0; k < K; ++k) v.launch(s);
+            for (int k = 0; k < Kv; ++k) v.launch(s);
             CK(hipEventRecord(e1, s));
             CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            v.us.push_back(ms * 1e3f / K);
+            v.us.push_back(ms * 1e3f / Kv);
         }
     CK(hipGetLastError());
     printf("rowbench: %lld boards after %d random plies, K=%d, %d reps (us per launch: min / median)\n", (long long)n, plies, K, reps);
