@@ -665,3 +665,45 @@ def test_step_random_many_accumulates_per_board_returns(auto_reset):
         a.step_random_many(3, returns=ret[:-1])
     L, s = a._lib, torch.cuda.current_stream().cuda_stream
     assert L.qttt_step_random_many(a.state.data_ptr(), 1, 0, 0, 0, None, None, None, 0, ret.data_ptr() + 2, n, 3, s) == -3
+
+
+def test_large_batch_shapes_of_export_and_node_info_on_ragged_offset_views():
+    """Above 384 K boards export runs two boards per lane and node_info / expand 1024-thread workgroups: an odd batch
+    size, outputs as views offset by one board (every alignment phase, the scalar-store paths), against the
+    whole-tensor results of the same kernels (which the oracle / the torch restatements pin elsewhere)."""
+    from qtttgym_amd import VecEnv
+    n = 400001
+    env = VecEnv(n, seed=21)
+    depth = (torch.arange(n, device="cuda") * 2654435761 % 11).to(torch.uint8)
+    a = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(10):
+        env.sample_actions(out=a)
+        a[depth <= t] = 0
+        env.step_raw(a)
+    ex = env.export_boards()
+    small = VecEnv.from_state(env.take(torch.arange(1000, device="cuda")).state, 1000)     # the same boards through the small-batch shape
+    sx = small.export_boards()
+    for k in ex:
+        assert torch.equal(ex[k][:1000], sx[k]), k
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    spec = dict((k, (dt, shp)) for k, dt, shp in VecEnv._EXPORT_SPEC)
+    order = ["moves", "n_moves", "board", "qmask", "n_q"]
+    bufs = {k: torch.full((n + 1,) + spec[k][1], 77, dtype=spec[k][0], device="cuda") for k in order}
+    assert L.qttt_export(env.state.data_ptr(), *[bufs[k][1:].data_ptr() for k in order], n, s) == 0
+    for k in order:
+        assert torch.equal(bufs[k][1:], ex[k]), k
+        assert bool((bufs[k][0] == 77).all()), k
+    info = env.node_info()
+    big = {"winner": torch.zeros(n + 1, dtype=torch.int8, device="cuda"), "terminal": torch.zeros(n + 1, dtype=torch.bool, device="cuda"),
+           "legal": torch.zeros(n + 1, dtype=torch.int64, device="cuda"), "key": torch.zeros(n + 1, dtype=torch.int64, device="cuda")}
+    env.node_info(out={k: v[1:] for k, v in big.items()})
+    si = small.node_info()
+    for k in big:
+        assert torch.equal(big[k][1:], info[k]) and int(big[k][0]) == 0, k
+        assert torch.equal(info[k][:1000], si[k]), k
+    act = torch.randint(0, 36, (n,), dtype=torch.uint8, device="cuda")
+    out, so = env.expand(act), small.expand(act[:1000].contiguous())
+    for k in ("n_children", "winner", "terminal", "legal", "key"):
+        assert torch.equal(out[k][:1000], so[k]), k
+    planes = lambda st, m: st.view(torch.int64).view(2, -1)[:, :m]
+    assert torch.equal(planes(out["child0"].state, n)[:, :1000], planes(so["child0"].state, 1000))
