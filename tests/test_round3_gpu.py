@@ -426,12 +426,12 @@ def test_two_ranks_random_fused_shards_equal_the_single_run_through_returns_gath
 
 # ---------------------------------------------------------------------------------------------------
 # hipGraph of step launches with the step index on the device (VecEnv.capture, qttt_env.step_counter)
-@pytest.mark.parametrize("n", [4096, 70001])
-def test_captured_random_steps_replay_with_a_fresh_step_index_every_time(n):
+@pytest.mark.parametrize("n,off", [(4096, 0), (70001, 0), (4099, (1 << 32) - 2000)])
+def test_captured_random_steps_replay_with_a_fresh_step_index_every_time(n, off):
     from qtttgym_amd import VecEnv
     T, R, seed = 9, 3, 21
-    ob, acts, rew, term = _oracle_random_steps(n, T * R + 2, seed, 0, True)
-    env = VecEnv(n, seed=seed, auto_reset=True)
+    ob, acts, rew, term = _oracle_random_steps(n, T * R + 2, seed, off, True)
+    env = VecEnv(n, seed=seed, auto_reset=True, board_offset=off)      # (ids crossing 2^32: two launch segments per node)
     a = torch.zeros((T, n, 2), dtype=torch.uint8, device="cuda")
     r = torch.zeros((T, n), dtype=torch.float32, device="cuda")
     tm = torch.zeros((T, n), dtype=torch.bool, device="cuda")
