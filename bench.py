@@ -404,9 +404,12 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
     act = torch.randint(0, 36, (n,), dtype=torch.uint8, device=dev)
     obs, ex, ni, cw, tn = env.observ(), env.export_boards(), env.node_info(), env.check_win(), env.turn()
     xp, ro, enc = env.expand(act), env.rollout(), env.encode()
+    env_in = VecEnv(n, device=dev, seed=args.seed)             # the target of the import row
     rows = [
         ("observe", "observe_kernel", lambda: env.observ(), sb + 30, "hbm"),
         ("export", "export_kernel", lambda: env.export_boards(out=ex), sb + 37, "hbm"),
+        ("import", "import_kernel", lambda: env_in.import_boards(ex["moves"], ex["n_moves"], ex["board"], ex["qmask"], ex["n_q"]),
+         sb + 37, "valu (tree rooting) + hbm"),
         ("turn", "export_kernel (n_moves only)", lambda: env.turn(out=tn), sb // 2 + 1, "launch"),
         ("check_win", "check_win_kernel", lambda: env.check_win(out=cw), sb // 2 + 2, "launch"),
         ("node_info", "node_info_kernel", lambda: env.node_info(out=ni), sb + 18, "valu (CPython tuple hash)"),

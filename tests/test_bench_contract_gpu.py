@@ -100,7 +100,7 @@ def test_bench_default_line_carries_the_legs():
                  "gym_1048576_boards", "random_1048576_boards", "random_fused_1048576_boards",
                  "random_fused_262144_boards", "random_fused_4096_boards", "config5_expand_node_info_rollout_65536_boards"):
         assert name in legs, name
-    for name in ("observe", "export", "turn", "check_win", "node_info", "expand", "rollout", "encode"):
+    for name in ("observe", "export", "import", "turn", "check_win", "node_info", "expand", "rollout", "encode"):
         assert "row_%s_1048576_boards" % name in legs, name
     assert legs["row_export_1048576_boards"]["algorithmic_bytes_per_board"] == sb + 37
     for l in d["legs"]:
