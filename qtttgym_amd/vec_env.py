@@ -85,7 +85,9 @@ class VecEnv:
     def use_device_step_counter(self):
         """Moves the step index into a device-side u32 that the step kernels read when they RUN
         (qttt_env.step_counter): launches captured in a hipGraph then use a fresh index on every replay.
-        Eager calls keep working; each of them advances the counter with one extra one-lane launch."""
+        Eager calls keep working; each of them advances the counter with one extra one-lane launch, and the
+        step launches that read the counter run in one shape (one board per lane, 256-thread workgroups): this is the
+        mode for small, launch-bound batches — at 1 M boards the ordinary path is ~20 % faster."""
         if self._ctr is None:
             with torch.cuda.device(self.device):
                 self._ctr = torch.tensor(self._step_host, dtype=torch.int32, device=self.device)
