@@ -219,7 +219,9 @@ typedef struct qttt_env {
     const uint32_t *step_counter;   /* nullable DEVICE u32: the step index a launch uses is step_idx + *step_counter,
                                        read when the kernel runs — so qttt_env_step calls captured in a hipGraph can be
                                        replayed (a graph node cannot carry a host-side step counter): capture node t with
-                                       step_idx = t and end the graph with qttt_counter_add(step_counter, T) */
+                                       step_idx = t and end the graph with qttt_counter_add(step_counter, T).  Such launches
+                                       run in one shape (one board per lane, 256-thread workgroups: graphs are for small,
+                                       launch-bound batches); calls with explicit bits need no step index and are unaffected */
 } qttt_env;
 #define QTTT_ENV_STEP         0     /* = qttt_step(actions, bits) */
 #define QTTT_ENV_STEP_OBSERVE 1     /* = qttt_step_observe(actions, bits) */
