@@ -210,18 +210,18 @@ def test_bench_self_launch_propagates_a_failing_rank():
     assert "no HIP device visible" in out.stderr or "needs 2 GPUs" in out.stderr
 
 
-def test_action_indexing_matches_the_reference_formulas():
-    """mcts.py:339-350: ind2move(n) = (i, j) by the closed form, move2ind its inverse (either order); the
-    package's table-based versions and the batched tensor forms agree with them (host logic, CPU)."""
-    import math
+def test_action_indexing_is_the_lexicographic_pair_order():
+    """mcts.py:339-350 index the 36 unordered pairs of squares in lexicographic order ((0,1), (0,2) … (7,8); the table
+    is printed in SURVEY.md Appendix A): ind2move enumerates exactly that order, move2ind is its inverse in either
+    argument order, and the batched tensor forms agree (host logic, CPU)."""
+    import itertools
     import torch
     from qtttgym_amd import ind2move, move2ind
     from qtttgym_amd.actions import action36_to_pairs, pairs_to_action36, legal_mask_to_bool
+    assert [ind2move(n) for n in range(36)] == list(itertools.combinations(range(9), 2))
     for n in range(36):
-        i = int((17 - math.sqrt(17 * 17 - 8 * n)) / 2)                 # the reference's arithmetic, restated
-        j = (2 * n + 2 - 15 * i + i * i) // 2
-        assert ind2move(n) == (i, j) and 0 <= i < j <= 8
-        assert move2ind(i, j) == n == move2ind(j, i) == (15 * i - i * i + 2 * j - 2) // 2
+        i, j = ind2move(n)
+        assert move2ind(i, j) == n == move2ind(j, i)
     assert [ind2move(n) for n in (0, 7, 8, 35)] == [(0, 1), (0, 8), (1, 2), (7, 8)]   # SURVEY Appendix A
     a = torch.tensor([0, 7, 8, 35, 36, 255], dtype=torch.uint8)
     p = action36_to_pairs(a)
