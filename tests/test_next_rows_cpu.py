@@ -71,3 +71,46 @@ def test_pyhash_matches_the_running_interpreter():
             mv = tuple((int(ob.b["moves"][i][j][0]), int(ob.b["moves"][i][j][1]), j)
                        for j in range(int(ob.b["n_moves"][i])))
             assert int(key[i]) == hash(b + mv)
+
+
+# ---------------------------------------------------------------------------------------------
+# The playout loop (MCTS._rollout's num_simulations loop, _simulate, _reward: mcts.py:166-176,185-209)
+# recorded from the reference's own mcts.py with its three random sources keyed by the build's counter
+# hash (tests/golden/make_golden_playout.py).
+@pytest.fixture(scope="module")
+def gp():
+    with np.load(os.path.join(ROOT, "tests", "golden", "playout_traces.npz")) as d:
+        return {k: d[k] for k in d.files}
+
+
+def playout_groups(gp):
+    """(seed, board_offset, step_idx0, slice of the parents) per recorded group."""
+    start = 0
+    for g in range(len(gp["g_seed"])):
+        n = int(gp["g_count"][g])
+        yield int(gp["g_seed"][g]), int(gp["g_offset"][g]), int(gp["g_step_idx0"][g]), slice(start, start + n)
+        start += n
+
+
+def test_oracle_rollout_reproduces_the_reference_simulate_loop(gp):
+    S, stride = int(gp["n_sims"]), int(gp["sim_stride"])
+    assert stride == 16                                              # QTTT_SIM_STRIDE, include/qttt.h
+    for seed, offset, step0, sl in playout_groups(gp):
+        ob = oracle.boards_from_arrays(gp["p_board"][sl], gp["p_moves"][sl], gp["p_n_moves"][sl],
+                                       gp["p_qmask"][sl], gp["p_n_q"][sl])
+        w, t, _, _ = oracle.node_info(ob)
+        assert np.array_equal(w, gp["p_winner"][sl]) and np.array_equal(t.astype(bool), gp["p_terminal"][sl])
+        total = np.zeros(ob.n, dtype=np.int64)
+        for s in range(S):
+            result, plies, final = oracle.rollout(ob, seed, step0 + s * stride, offset)
+            assert np.array_equal(result, gp["s_result"][sl, s])              # MCTS._reward of the end node
+            assert np.array_equal(plies, gp["s_plies"][sl, s])                # termination + the 9-ply cap
+            assert np.array_equal(final.board, gp["s_f_board"][sl, s])
+            assert np.array_equal(final.moves, gp["s_f_moves"][sl, s])
+            assert np.array_equal(final.n_moves, gp["s_f_n_moves"][sl, s])
+            total += result
+        # what _rollout hands to _backpropogate: r_tot / num_simulations, r_tot += r if leaf.turn else -r
+        sign = np.where(gp["p_turn"][sl], 1, -1)
+        assert np.array_equal(sign * total / float(S), gp["p_value"][sl])
+    # terminal parents play nothing; the longest playout is the nine plies from the empty board
+    assert (gp["s_plies"][gp["p_terminal"]] == 0).all() and gp["s_plies"].max() == 9
