@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define QTTT_ABI_VERSION 3
+#define QTTT_ABI_VERSION 4
 
 #define QTTT_ERR_NULL   (-1)
 #define QTTT_ERR_SIZE   (-2)
@@ -164,22 +164,35 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx,
  *   terminal u8[n] line or len(moves) == 9                     (mcts.py:65)
  *   legal u64[n]   bit a = action a in GameState.actions       (mcts.py:20-27, ind2move order)
  *   key i64[n]     GameState.__hash__ (mcts.py:93-94) = CPython (>= 3.8) hash(tuple(board) +
- *                  tuple(moves)), bit-exact, so keys match a host-side transposition table
- * Every output is nullable; only what is asked for is computed (the key is ~3/4 of the work). */
+ *                  tuple(moves)), bit-exact, so keys match a host-side transposition table built by
+ *                  reference code (~3/4 of the kernel's work when asked for)
+ *   state_key u64[n]  the native position key = qttt_state_key() of the board's two packed words: the
+ *                  reference only ever uses __hash__ / __eq__ as dict keys (mcts.py:93-97,160-164,210-221),
+ *                  i.e. needs "equal keys <=> equal (board, moves)", which this key gives at a twentieth
+ *                  of the arithmetic — for transposition tables that live on the device
+ * Every output is nullable; only what is asked for is computed. */
 int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,
-                   int64_t *key, int64_t n, void *stream);
+                   int64_t *key, uint64_t *state_key, int64_t n, void *stream);
+
+/* The native position key of one board from its packed words P[i], Q[i] (host-callable, no device work).
+ * Equal for two boards iff their (board, moves) are equal (up to 64-bit collisions): the packed state is a
+ * canonical form of (board, moves) whether it was reached by stepping or written by qttt_import; the cached
+ * qstructs (list order is not part of a position) and the done bit are left out of the mix. */
+uint64_t qttt_state_key(uint64_t plane_p_word, uint64_t plane_q_word);
 
 /* MCTS._step (mcts.py:233-267) for n (state, action) pairs, both collapse branches at once.
  *   action36 u8[n]    index into ind2move order (mcts.py:339-343); > 35 is illegal
  *   child0, child1    packed states, qttt_state_bytes(n) each (child 1 meaningful when n_children == 2)
  *   n_children u8[n]  0 = make_move raises (children = copies of the parent), 1 = no collapse,
  *                     2 = collapse: child 0 = closing move on min(a,b) (bit 0), child 1 = on max(a,b)
- *   winner i8[n,2], terminal u8[n,2], legal u64[n,2], key i64[n,2]: as qttt_node_info, per child
+ *   winner i8[n,2], terminal u8[n,2], legal u64[n,2], key i64[n,2], state_key u64[n,2]: as qttt_node_info,
+ *                     per child (-1 / 0 / 0 / 0 / 0 for a child that does not exist); each nullable
  * The reference returns the two children in random order; compare as a set.  winner / terminal must be
- * 2-byte and legal / key 16-byte aligned (one vector store per pair of children; QTTT_ERR_ACTION otherwise). */
+ * 2-byte and legal / key / state_key 16-byte aligned (one vector store per pair of children;
+ * QTTT_ERR_ACTION otherwise). */
 int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *child1,
                 uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
-                int64_t *key, int64_t n, void *stream);
+                int64_t *key, uint64_t *state_key, int64_t n, void *stream);
 
 /* MCTS._simulate (mcts.py:185-198) with the uniform priors of mcts.py:287-292: uniform-legal random
  * playout to the end with the board in registers; ply p draws action and collapse branch from the
@@ -197,6 +210,24 @@ int qttt_rollout(const void *state, uint64_t seed, uint32_t step_idx0, int64_t b
 #define QTTT_SIM_STRIDE 16u      /* a playout has at most 9 plies: simulations use disjoint step indices */
 int qttt_rollout_many(const void *state, uint64_t seed, uint32_t step_idx0, int64_t board_offset,
                       int32_t n_sims, int8_t *result, uint8_t *plies, int64_t n, void *stream);
+
+/* One MCTS._rollout below the selected node in ONE launch (mcts.py:166-176: select -> _expand_child -> num_simulations
+ * x _simulate from the leaf -> the value handed to _backpropogate; :210-221,233-267): qttt_expand of the n
+ * (state, action) pairs — same outputs, child0 / child1 nullable here too — and n_sims playouts from EACH child:
+ * exactly qttt_rollout_many(child0, seed, step_idx0, board_offset, n_sims) and
+ * qttt_rollout_many(child1, seed, step_idx0 + n_sims * QTTT_SIM_STRIDE, board_offset, n_sims).
+ *   value_sum i32[n,2]        sum over the child's simulations of `r if leaf.turn else -r` (mcts.py:174); divide by
+ *                             n_sims for the value of mcts.py:176.  leaf.turn is True after an even number of real
+ *                             moves (MCTS.reset's len(moves) % 2 == 0, flipped once per _step: mcts.py:140,243).
+ *                             0 for a child that does not exist
+ *   result i8[n,2,n_sims]     nullable: every simulation's MCTS._reward (0 for a child that does not exist)
+ * 1 <= n_sims <= QTTT_EXPAND_ROLLOUT_MAX_SIMS (a workgroup owns whole pairs; the reference's default is 10). */
+#define QTTT_EXPAND_ROLLOUT_MAX_SIMS 128
+int qttt_expand_rollout(const void *state, const uint8_t *action36, void *child0, void *child1,
+                        uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                        int64_t *key, uint64_t *state_key, uint64_t seed, uint32_t step_idx0,
+                        int64_t board_offset, int32_t n_sims, int32_t *value_sum, int8_t *result,
+                        int64_t n, void *stream);
 
 /* GameState.to_vector (mcts.py:67-85) -> vec f32[n,18,10]; action_mask (mcts.py:87-91) ->
  * mask u8[n,36] (nullable).  The reference builds float64; values are 0, 1 and 1/3 rounded to f32. */

@@ -7,11 +7,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # QTTT_LIB_PATH: load another build of the same ABI (A/B diagnostics); default = the in-tree build
 LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_AUTO_RESET = 1
 FLAG_FUSED = 2
 BOARD_RECORD_BYTES = 64
 SIM_STRIDE = 16
+EXPAND_ROLLOUT_MAX_SIMS = 128
 OP_MAKE_MOVE, OP_UPDATE_QSTRUCTS, OP_CHECK_WIN = 0, 1, 2
 
 class EnvRecord(ctypes.Structure):
@@ -44,8 +45,11 @@ SIGNATURES = {
     "qttt_board_op": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_board_op_sync": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
-    "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "qttt_expand": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_state_key": (_u64, [_u64, _u64]),
+    "qttt_expand": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qttt_expand_rollout": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u32, _i64, _i32, _vp, _vp,
+                                   _i64, _vp]),
     "qttt_rollout": (_i32, [_vp, _u64, _u32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "qttt_rollout_many": (_i32, [_vp, _u64, _u32, _i64, _i32, _vp, _vp, _i64, _vp]),
     "qttt_encode": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -157,9 +157,33 @@ class Board:
         """Takes the attributes back from an out record (bytes)."""
         r = o
         n = min(r[18], 9)
-        self.moves = list(zip(r[0:2 * n:2], r[1:2 * n:2], range(n)))
-        self.board[:] = [_I8[x] for x in r[19:28]]         # in place: env.py:71,82 aliasing
-        self.qstructs = [set(_SQUARES[(r[30 + 2 * k] | r[31 + 2 * k] << 8) & 511]) for k in range(min(r[28], 4))]
+        # All three attributes are updated IN PLACE, as the reference does (board.py:19,25 append to .moves,
+        # :53-54 write into .board, :56-69 pop / assign / append on .qstructs): a caller that took `b.moves`,
+        # `b.board` or `b.qstructs` before the call sees the move afterwards (env.py:71,82 aliases .board).
+        self.moves[:] = zip(r[0:2 * n:2], r[1:2 * n:2], range(n))
+        self.board[:] = [_I8[x] for x in r[19:28]]
+        new = [set(_SQUARES[(r[30 + 2 * k] | r[31 + 2 * k] << 8) & 511]) for k in range(min(r[28], 4))]
+        old = self.qstructs
+        if old:
+            # the set OBJECTS too: an untouched component stays the object it was (board.py:56,61 only pop
+            # the others' neighbour), "add to sets" grows its set in place (board.py:68-69); a union is a
+            # new set (board.py:60), as in the reference
+            spare = list(old)
+            for k, s in enumerate(new):
+                for t in spare:
+                    if t == s:
+                        new[k] = t
+                        spare.remove(t)
+                        break
+            if len(new) == len(old):
+                for k, s in enumerate(new):
+                    if not any(s is t for t in old):
+                        grown = [t for t in spare if t < s]
+                        if len(grown) == 1:
+                            grown[0].update(s)
+                            new[k] = grown[0]
+                            spare.remove(grown[0])
+        self.qstructs[:] = new
         # the out record carries check_win of the new state (a function of .board alone,
         # board.py:71-115): remembered, keyed by the board it belongs to
         self._win = (tuple(self.board), _I8[r[49]], _I8[r[50]])

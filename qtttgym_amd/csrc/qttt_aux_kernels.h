@@ -309,7 +309,8 @@ __device__ __forceinline__ void cold_from_attrs(const uint8_t *moves, u32 n_move
 //     give 0 by themselves);
 //   * the explicit autofill move (board.py:22-25) stripped back to the implicit form;
 //   * the rooted forest: the un-collapsed moves are inserted in round order exactly as the step inserts a move —
-//     re-root the tree of one end (path reversal, the step's own walk), hang it under the other end;
+//     re-root the tree of one end (path reversal, the step's own walk, the step's own choice of the end), hang it
+//     under the other end: import(export(state)) is the state again, bit for bit;
 //   * qstructs from the caller's masks as they are; done = a line or nine moves (env.py:51).
 // Valid (reachable) attribute sets give a state whose export is the input again; anything else gives some state
 // without faults or unbounded loops (the walk is bounded by nine nodes).  The single-record Board façade keeps the
@@ -371,13 +372,23 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
                           ((u64)((u32)(qm >> 32) & 0x1FFu) << 18) | ((u64)((u32)(qm >> 48) & 0x1FFu) << 27);
     const u64 comps = nqc >= 4u ? comps_all : comps_all & ((1ull << (9u * nqc)) - 1ull);
     // ---- the rooted forest: insert the un-collapsed moves in round order (the step's own path reversal)
+    // The child end is chosen as the step chose it when the move was played (step_child_end4: hi, unless only lo
+    // was free of un-collapsed moves), so that an imported position is bit for bit the state stepping reaches —
+    // which is what lets state_key() stand for (board, moves).  "In a component then" = touched by an earlier move
+    // that is still un-collapsed now: a component collapses as a whole, so a square whose old component is gone is
+    // classical, and so would be every move on it.  (A move of round 8 always closes a cycle: never live.)
     u64 P = ((u64)W << 2) | ((u64)c8 << 34);
+    u32 touched = 0;
 #pragma unroll
     for (u32 t = 0; t < 8u; ++t) {
         const u32 pr = (u32)((t < 4u ? m03 : m47) >> (16u * (t & 3u))) & 0xFFFFu;
         const u32 lo = pr & 0xFFu, hi = pr >> 8;
-        if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u)
-            P = step_reroot(P, Q0, hi * 4u, t * 4u);                     // hi becomes the child end of move t
+        if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u) {
+            const u32 both = (1u << lo) | (1u << hi);
+            const u32 x = (touched & both) == (1u << hi) ? lo : hi;
+            P = step_reroot(P, Q0, x * 4u, t * 4u);                      // x becomes the child end of move t
+            touched |= both;
+        }
     }
     u32 P0 = (u32)P, P1 = (u32)(P >> 32) & 0x3Fu;
     P1 |= (n_real << P1_N_SHIFT) | (((u32)(comps >> 32) & 0xFu) << P1_CHI_SHIFT) | (last_x << P1_LX_SHIFT) | (cl << P1_CL_SHIFT);

@@ -476,44 +476,74 @@ int qttt_sample_actions(const void *state, uint64_t seed, uint32_t step_idx, int
 }
 
 int qttt_node_info(const void *state, int8_t *winner, uint8_t *terminal, uint64_t *legal,
-                   int64_t *key, int64_t n, void *stream) {
+                   int64_t *key, uint64_t *state_key, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state) return QTTT_ERR_NULL;
-    if (!winner && !terminal && !legal && !key) return 0;                   // nothing asked for
+    if (!winner && !terminal && !legal && !key && !state_key) return 0;      // nothing asked for
     Planes p = planes(const_cast<void *>(state), n);
     // workgroup size by batch (tools/rowbench, us per launch, 256 / 512 / 1024 threads: 1 M boards 11.7 / 11.2 / 10.5 —
     // the 12 KB of tables are filled once per workgroup; 64 K boards 4.6 / 4.7 / 5.8 — latency-bound).  Measured and not
     // adopted: a 1 000-entry table of the accumulator after the first three board elements (three multiply steps
     // less per board): 10.2 us with 1024 threads, but every smaller shape and expand lose as much to the 8 KB fill.
-    if (n >= 384 * 1024)
-        hipLaunchKernelGGL((node_info_kernel<1024>), dim3(blocks_for((n + 1) / 2, 1024)), dim3(1024), 0, (hipStream_t)stream,
-                           p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
-    else
-        hipLaunchKernelGGL((node_info_kernel<256>), dim3(blocks_for((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream,
-                           p.P, p.Q, winner, terminal, (u64 *)legal, key, n);
+#define QTTT_NI(BLK, PK) hipLaunchKernelGGL((node_info_kernel<BLK, PK>), dim3(blocks_for((n + 1) / 2, BLK)), dim3(BLK), 0, \
+                                            (hipStream_t)stream, p.P, p.Q, winner, terminal, (u64 *)legal, key, (u64 *)state_key, n)
+    if (n >= 384 * 1024) { if (key) QTTT_NI(1024, true); else QTTT_NI(1024, false); }
+    else                 { if (key) QTTT_NI(256, true);  else QTTT_NI(256, false); }
+#undef QTTT_NI
     return launch_status();
+}
+
+uint64_t qttt_state_key(uint64_t plane_p_word, uint64_t plane_q_word) { return state_key(plane_p_word, (u32)plane_q_word); }
+
+// the per-child rows [n,2] are written as one vector per pair
+static int expand_rows_misaligned(const int8_t *winner, const uint8_t *terminal, const uint64_t *legal, const int64_t *key,
+                                  const uint64_t *state_key) {
+    return ((uintptr_t)winner & 1u) || ((uintptr_t)terminal & 1u) || ((uintptr_t)legal & 15u) || ((uintptr_t)key & 15u) ||
+           ((uintptr_t)state_key & 15u);
 }
 
 int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *child1,
                 uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
-                int64_t *key, int64_t n, void *stream) {
+                int64_t *key, uint64_t *state_key, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
-    if (!state || !action36 || !child0 || !child1 || !n_children || !winner || !terminal || !legal || !key)
-        return QTTT_ERR_NULL;
-    // the per-child rows [n,2] are written as one vector per pair
-    if (((uintptr_t)winner & 1u) || ((uintptr_t)terminal & 1u) || ((uintptr_t)legal & 15u) || ((uintptr_t)key & 15u))
-        return QTTT_ERR_ACTION;
+    if (!state || !action36 || !child0 || !child1) return QTTT_ERR_NULL;
+    if (expand_rows_misaligned(winner, terminal, legal, key, state_key)) return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
+    const ExpandOut o = {n_children, winner, terminal, (u64 *)legal, key, (u64 *)state_key};
     // workgroup size by batch, as node_info (tools/rowbench, 256 / 512 / 1024 threads: 1 M pairs 27.4 / 26.6 / 25.9 us,
     // 64 K pairs 5.6 / 6.0 / 7.9)
-    if (n >= 384 * 1024)
-        hipLaunchKernelGGL((expand_kernel<1024>), dim3(blocks_for(n, 1024)), dim3(1024), 0, (hipStream_t)stream,
-                           p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner, terminal, (u64 *)legal, key, n);
-    else
-        hipLaunchKernelGGL((expand_kernel<256>), dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                           p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, n_children, winner, terminal, (u64 *)legal, key, n);
+#define QTTT_EX(BLK, PK) hipLaunchKernelGGL((expand_kernel<BLK, PK>), dim3(blocks_for(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, \
+                                            p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, n)
+    if (n >= 384 * 1024) { if (key) QTTT_EX(1024, true); else QTTT_EX(1024, false); }
+    else                 { if (key) QTTT_EX(256, true);  else QTTT_EX(256, false); }
+#undef QTTT_EX
+    return launch_status();
+}
+
+int qttt_expand_rollout(const void *state, const uint8_t *action36, void *child0, void *child1,
+                        uint8_t *n_children, int8_t *winner, uint8_t *terminal, uint64_t *legal,
+                        int64_t *key, uint64_t *state_key, uint64_t seed, uint32_t step_idx0,
+                        int64_t board_offset, int32_t n_sims, int32_t *value_sum, int8_t *result,
+                        int64_t n, void *stream) {
+    constexpr int BLK = 256;
+    if (n < 0 || board_offset < 0 || n_sims < 1 || n_sims > QTTT_EXPAND_ROLLOUT_MAX_SIMS) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !action36 || !value_sum) return QTTT_ERR_NULL;
+    if (expand_rows_misaligned(winner, terminal, legal, key, state_key) || ((uintptr_t)value_sum & 3u)) return QTTT_ERR_ACTION;
+    Planes p = planes(const_cast<void *>(state), n);
+    Planes c0 = {nullptr, nullptr}, c1 = {nullptr, nullptr};
+    if (child0) c0 = planes(child0, n);
+    if (child1) c1 = planes(child1, n);
+    const ExpandOut o = {n_children, winner, terminal, (u64 *)legal, key, (u64 *)state_key};
+    const u32 ppb = (u32)(BLK / (2 * n_sims));                    // whole pairs per workgroup
+    const unsigned grid = (unsigned)((n + ppb - 1) / ppb);
+#define QTTT_XR(PK) hipLaunchKernelGGL((expand_rollout_kernel<BLK, PK>), dim3(grid), dim3(BLK), 0, (hipStream_t)stream,     \
+                                       p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, (u64)seed, step_idx0,               \
+                                       (u64)board_offset, (u32)n_sims, ppb, value_sum, result, n)
+    if (key) QTTT_XR(true); else QTTT_XR(false);
+#undef QTTT_XR
     return launch_status();
 }
 

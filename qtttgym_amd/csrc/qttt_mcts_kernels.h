@@ -22,11 +22,14 @@ __constant__ PairLut g_pair_lut = PairLut();
 // Two boards per lane (one 16-byte load per plane, 16-byte stores of the two legal masks and the two
 // keys): the CPython tuple hash is a dependent chain per board, two chains in one lane interleave
 // (fast_py_hash_pair).  The last board of an odd batch is handled alone.
-template <int BLOCK>
+// PYKEY: the CPython-exact key (GameState.__hash__, for host-side dicts built by reference code) is its own
+// instantiation: without it the kernel carries neither the 5.9 KB table nor the chain.  `skey` is the native
+// 64-bit position key (state_key(): a mix of the packed words, for device-side tables).
+template <int BLOCK, bool PYKEY>
 __global__ __launch_bounds__(BLOCK) void node_info_kernel(
     const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal, u64 *legal,
-    int64_t *key, int64_t n) {
-    __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    int64_t *key, u64 *skey, int64_t n) {
+    __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
     __shared__ u64 ltbl[512];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;   // boards 2j, 2j + 1
@@ -34,19 +37,33 @@ __global__ __launch_bounds__(BLOCK) void node_info_kernel(
     typedef Vec<u64, 2> V64;
     V64 p, q;
     p.v[0] = p.v[1] = q.v[0] = q.v[1] = 0ull;
+    const bool want_q = PYKEY || skey != nullptr;                       // plane Q: only the keys read it (the x nibbles)
     if (i0 + 1 < n) {                                                   // requested before the table fills
         p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]);
-        if (key) q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);   // plane Q: only the hash reads it (the x nibbles)
+        if (want_q) q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);
     } else if (i0 < n) {
         p.v[0] = pP[i0];
-        if (key) q.v[0] = pQ[i0];
+        if (want_q) q.v[0] = pQ[i0];
     }
-    if (key) fill_pyhash_lut<BLOCK>(htbl);
+    if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
     if (legal) fill_legal_lut<BLOCK>(ltbl);
-    fill_line_lut<BLOCK>(lut);                       // ends with the workgroup barrier
+    if (winner || terminal || legal || PYKEY) fill_line_lut<BLOCK>(lut);   // ends with the workgroup barrier
     if (i0 >= n) return;
-    const Lite sa = lite_unpack(p.v[0]), sb = lite_unpack(p.v[1]);
     const bool two = i0 + 1 < n;
+    typedef Vec<u64, 2> V64x;
+    if (skey) {                                            // needs no table: out first
+        const u64 ka = state_key(p.v[0], (u32)q.v[0]), kb = state_key(p.v[1], (u32)q.v[1]);
+        if (two && (reinterpret_cast<uintptr_t>(skey) & 15u) == 0u) {
+            V64x k2;
+            k2.v[0] = ka; k2.v[1] = kb;
+            store_stream(&reinterpret_cast<V64x *>(skey)[j], k2);
+        } else {
+            skey[i0] = ka;
+            if (two) skey[i0 + 1] = kb;
+        }
+    }
+    if (!(winner || terminal || legal || PYKEY)) return;
+    const Lite sa = lite_unpack(p.v[0]), sb = lite_unpack(p.v[1]);
     if (winner || terminal) {
         int wa, ta, wb, tb;
         lite_update_winner(sa, lut, wa, ta);
@@ -59,7 +76,6 @@ __global__ __launch_bounds__(BLOCK) void node_info_kernel(
             if (terminal) { terminal[i0] = (uint8_t)ta; if (two) terminal[i0 + 1] = (uint8_t)tb; }
         }
     }
-    typedef Vec<u64, 2> V64x;
     if (legal) {
         const u64 la = ltbl[sa.cl], lb = ltbl[sb.cl];
         if (two && (reinterpret_cast<uintptr_t>(legal) & 15u) == 0u) {
@@ -71,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void node_info_kernel(
             if (two) legal[i0 + 1] = lb;
         }
     }
-    if (key) {                                             // the expensive part: skipped when the caller keeps no table
+    if (PYKEY) {                                           // the expensive part: skipped when the caller keeps no host table
         int64_t ka, kb;
         fast_py_hash_pair(sa, (u32)(p.v[0] >> 32), (u32)q.v[0], sb, (u32)(p.v[1] >> 32), (u32)q.v[1], htbl, ka, kb);
         if (two && (reinterpret_cast<uintptr_t>(key) & 15u) == 0u) {
@@ -87,22 +103,68 @@ __global__ __launch_bounds__(BLOCK) void node_info_kernel(
 
 // MCTS._step (mcts.py:233-267): both values of the collapse bit computed directly instead of
 // re-sampling make_move until the other branch appears.  The two children's bookkeeping (winner, legal
-// mask, key) is computed as a pair — two independent hash chains in one lane, as in node_info — and
+// mask, keys) is computed as a pair — with PYKEY two independent hash chains in one lane, as in node_info — and
 // masked by n_children afterwards (child 1 is a valid state even when there is no collapse: it equals
-// child 0).
-template <int BLOCK>
+// child 0).  Every per-child output is nullable; PYKEY (the CPython-exact key) is its own instantiation.
+struct ExpandOut {
+    uint8_t *n_children;        // [n]
+    int8_t *winner;             // [n,2]
+    uint8_t *terminal;          // [n,2]
+    u64 *legal;                 // [n,2]
+    int64_t *key;               // [n,2] CPython tuple hash (PYKEY)
+    u64 *skey;                  // [n,2] native position key
+};
+// the bookkeeping of the two children of one pair, from their packed words (shared by expand_kernel and
+// expand_rollout_kernel's writer lanes)
+template <bool PYKEY>
+__device__ __forceinline__ void expand_bookkeeping(u32 kids, const u64 kidP[2], const u64 kidQ[2], const ExpandOut &o, int64_t i,
+                                                   const uint8_t *lut, const u64 *htbl, const u64 *ltbl) {
+    typedef Vec<u64, 2> V64;
+    const bool h0 = kids >= 1u, h1 = kids >= 2u;
+    if (o.n_children) o.n_children[i] = (uint8_t)kids;
+    if (o.skey) {
+        V64 k2;
+        k2.v[0] = h0 ? state_key(kidP[0], (u32)kidQ[0]) : 0ull;
+        k2.v[1] = h1 ? state_key(kidP[1], (u32)kidQ[1]) : 0ull;
+        store_stream(&reinterpret_cast<V64 *>(o.skey)[i], k2);
+    }
+    if (!(o.winner || o.terminal || o.legal || PYKEY)) return;
+    const Lite s0 = lite_unpack(kidP[0]), s1 = lite_unpack(kidP[1]);
+    if (o.winner || o.terminal) {
+        int w0, t0, w1, t1;
+        lite_update_winner(s0, lut, w0, t0);
+        lite_update_winner(s1, lut, w1, t1);
+        const u32 wv = (u32)((h0 ? w0 : -1) & 0xFF) | ((u32)((h1 ? w1 : -1) & 0xFF) << 8);
+        const u32 tv = (h0 ? (u32)t0 : 0u) | ((h1 ? (u32)t1 : 0u) << 8);
+        if (o.winner) reinterpret_cast<uint16_t *>(o.winner)[i] = (uint16_t)wv;      // [n,2] rows: 2-byte / 16-byte aligned by the host check
+        if (o.terminal) reinterpret_cast<uint16_t *>(o.terminal)[i] = (uint16_t)tv;
+    }
+    if (o.legal) {
+        V64 l2;
+        l2.v[0] = h0 ? ltbl[s0.cl] : 0ull; l2.v[1] = h1 ? ltbl[s1.cl] : 0ull;
+        store_stream(&reinterpret_cast<V64 *>(o.legal)[i], l2);
+    }
+    if (PYKEY) {
+        int64_t k0, k1;
+        fast_py_hash_pair(s0, (u32)(kidP[0] >> 32), (u32)kidQ[0], s1, (u32)(kidP[1] >> 32), (u32)kidQ[1], htbl, k0, k1);
+        V64 k2;
+        k2.v[0] = h0 ? (u64)k0 : 0ull;     k2.v[1] = h1 ? (u64)k1 : 0ull;
+        store_stream(&reinterpret_cast<V64 *>(o.key)[i], k2);
+    }
+}
+
+template <int BLOCK, bool PYKEY>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(
     const u64 *pP, const u64 *pQ, const uint8_t *action36,
-    u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, uint8_t *n_children,
-    int8_t *winner, uint8_t *terminal, u64 *legal, int64_t *key, int64_t n) {
+    u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, ExpandOut out, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    __shared__ u64 htbl[PYHASH_LUT_WORDS];
+    __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
     __shared__ u64 ltbl[512];
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;  // requested before the table fills
     const u32 a = i < n ? (u32)action36[i] : 0u;
-    fill_pyhash_lut<BLOCK>(htbl);
-    fill_legal_lut<BLOCK>(ltbl);
+    if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
+    if (out.legal) fill_legal_lut<BLOCK>(ltbl);
     fill_line_lut<BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
@@ -115,26 +177,9 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(
     kidP[0] = (u64)P0a | ((u64)P1a << 32);
     kidP[1] = (u64)P0b | ((u64)P1b << 32);
     kidQ[0] = kidQ[1] = (u64)Q0 | ((u64)Q1 << 32);
-    n_children[i] = (uint8_t)kids;
     store_stream(&c0P[i], kidP[0]); store_stream(&c0Q[i], kidQ[0]);
     store_stream(&c1P[i], kidP[1]); store_stream(&c1Q[i], kidQ[1]);
-    const Lite s0 = lite_unpack(kidP[0]), s1 = lite_unpack(kidP[1]);
-    int w0, t0, w1, t1;
-    lite_update_winner(s0, lut, w0, t0);
-    lite_update_winner(s1, lut, w1, t1);
-    int64_t k0, k1;
-    fast_py_hash_pair(s0, (u32)(kidP[0] >> 32), (u32)kidQ[0], s1, (u32)(kidP[1] >> 32), (u32)kidQ[1], htbl, k0, k1);
-    const bool h0 = kids >= 1u, h1 = kids >= 2u;
-    const u32 wv = (u32)((h0 ? w0 : -1) & 0xFF) | ((u32)((h1 ? w1 : -1) & 0xFF) << 8);
-    const u32 tv = (h0 ? (u32)t0 : 0u) | ((h1 ? (u32)t1 : 0u) << 8);
-    reinterpret_cast<uint16_t *>(winner)[i] = (uint16_t)wv;            // [n,2] rows: 2-byte / 16-byte aligned by the host check
-    reinterpret_cast<uint16_t *>(terminal)[i] = (uint16_t)tv;
-    typedef Vec<u64, 2> V64;
-    V64 l2, k2;
-    l2.v[0] = h0 ? ltbl[s0.cl] : 0ull; l2.v[1] = h1 ? ltbl[s1.cl] : 0ull;
-    k2.v[0] = h0 ? (u64)k0 : 0ull;     k2.v[1] = h1 ? (u64)k1 : 0ull;
-    store_stream(&reinterpret_cast<V64 *>(legal)[i], l2);
-    store_stream(&reinterpret_cast<V64 *>(key)[i], k2);
+    expand_bookkeeping<PYKEY>(kids, kidP, kidQ, out, i, lut, htbl, ltbl);
 }
 
 // MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
@@ -205,6 +250,80 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_many_kernel(
     lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, t);
     result[j] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));
     if (plies) plies[j] = (uint8_t)played;
+}
+
+// One MCTS._rollout below the selected node (mcts.py:166-176 with _select's expansion, :210-221,233-267) in ONE launch:
+// expand (state, action) into its one or two children, the children's bookkeeping, and n_sims playouts FROM EACH
+// CHILD — qttt_expand followed by qttt_rollout_many on child 0 (step indices from step_idx0) and on child 1 (from
+// step_idx0 + n_sims * QTTT_SIM_STRIDE), bit for bit.  One lane per (pair, simulation, child): lanes 2k, 2k + 1 are the
+// two children of one (pair, simulation), so a batch of 65 536 pairs with one playout per child is two waves per
+// SIMD instead of one with twice the chain; a workgroup owns BLOCK / (2 n_sims) whole pairs, so the per-child sums
+// are LDS adds.  Every lane redoes the (cheap) expansion of its pair; the lane of (simulation 0, child 0) writes the
+// pair's children and bookkeeping.
+//   value_sum i32[n,2]: sum over the child's simulations of `r if leaf.turn else -r` (mcts.py:174; leaf.turn is
+//   True after an even number of real moves: reset's len(moves) % 2 == 0 flipped once per _step, mcts.py:140,243);
+//   0 for a child that does not exist.  result i8[n,2,n_sims] (nullable): every simulation's MCTS._reward.
+template <int BLOCK, bool PYKEY>
+__global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
+    const u64 *pP, const u64 *pQ, const uint8_t *action36,
+    u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, ExpandOut out,
+    u64 seed, u32 step_idx0, u64 board_offset, u32 n_sims, u32 pairs_per_block,
+    int32_t *value_sum, int8_t *result, int64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    __shared__ uint8_t nth9[512 * 9];
+    __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
+    __shared__ u64 ltbl[512];
+    __shared__ int acc[BLOCK];                                  // [pair of the workgroup][child]
+    const u32 per_pair = 2u * n_sims;
+    const u32 pl = threadIdx.x / per_pair;                      // pair of the workgroup
+    const u32 rem = threadIdx.x - pl * per_pair;
+    const u32 sim = rem >> 1, child = rem & 1u;
+    const int64_t i = (int64_t)blockIdx.x * pairs_per_block + pl;
+    const bool valid = pl < pairs_per_block && i < n;
+    const int64_t il = valid ? i : 0;
+    const u64 P = pP[il], Q = pQ[il];                           // 2 n_sims neighbouring lanes read the same 16 bytes
+    const u32 a = (u32)action36[il];
+    acc[threadIdx.x] = 0;
+    fill_policy_lut<BLOCK>(plut);
+    fill_nth9<BLOCK>(nth9);
+    if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
+    if (out.legal) fill_legal_lut<BLOCK>(ltbl);
+    fill_line_lut<BLOCK>(lut);                                  // ends with the workgroup barrier
+    int r = 0;
+    u32 kids = 0;
+    if (valid) {
+        const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;
+        const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
+        u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b;
+        kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b);
+        if (rem == 0u) {                                        // this pair's writer
+            u64 kidP[2], kidQ[2];
+            kidP[0] = (u64)P0a | ((u64)P1a << 32);
+            kidP[1] = (u64)P0b | ((u64)P1b << 32);
+            kidQ[0] = kidQ[1] = (u64)Q0 | ((u64)Q1 << 32);
+            if (c0P) { c0P[i] = kidP[0]; c0Q[i] = kidQ[0]; }
+            if (c1P) { c1P[i] = kidP[1]; c1Q[i] = kidQ[1]; }
+            expand_bookkeeping<PYKEY>(kids, kidP, kidQ, out, i, lut, htbl, ltbl);
+        }
+        if (child < kids) {
+            u32 P0 = child ? P0b : P0a, P1 = child ? P1b : P1a;
+            playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed,
+                    step_idx0 + (child * n_sims + sim) * QTTT_SIM_STRIDE, lut, plut, nth9);
+            int w, t;
+            lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, t);
+            r = w < 0 ? 0 : (w ? 1 : -1);                       // MCTS._reward, mcts.py:200-209
+            // leaf.turn (mcts.py:174): the child has one real move more than the parent
+            const u32 child_real = ((child ? P1b : P1a) >> P1_N_SHIFT) & 0xFu;
+            if (r) atomicAdd(&acc[pl * 2u + child], (child_real & 1u) ? -r : r);
+        }
+        if (result) result[(i * 2 + child) * (int64_t)n_sims + sim] = (int8_t)r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u * pairs_per_block) {
+        const int64_t o = (int64_t)blockIdx.x * pairs_per_block * 2 + threadIdx.x;
+        if (o < 2 * n) value_sum[o] = acc[threadIdx.x];
+    }
 }
 
 // GameState.to_vector (mcts.py:67-85) as f32[18][10] and action_mask (mcts.py:87-91).

@@ -147,6 +147,23 @@ __device__ inline u32 collapse_bit_of(u32 x) {
     return x >> 31;
 }
 
+// ------------------------------------------------------------------ native 64-bit position key
+// GameState.__hash__ / __eq__ (mcts.py:93-97) are only ever dict keys (mcts.py:160-164,210-221): what a search
+// needs is "equal keys <=> equal (board, moves)".  The packed state already is a canonical form of
+// (board, moves) — reached by stepping or written by qttt_import, every field below is a function of the move
+// sequence and of where the collapsed moves landed — so the key is a mix of the state's own
+// words: three 64-bit multiplies instead of the 9 + n dependent multiply steps of CPython's tuple hash.
+// Left out: the cached qstructs (plane Q's high word and P1 bits 12..15: list ORDER is not part of a
+// position's identity and an importing caller may hand them over in another order) and the done bit.
+constexpr u64 KEY_P_MASK = ~((0xFull << (32u + P1_CHI_SHIFT)) | ((u64)P1_DONE << 32));
+__host__ __device__ inline u64 state_key(u64 P, u32 Q0) {
+    u64 h = (P & KEY_P_MASK) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h += (u64)Q0 * 0xD6E8FEB86659FD93ull;
+    h *= 0xBF58476D1CE4E5B9ull;
+    return h ^ (h >> 32);
+}
+
 // ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
 // rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4.
 // nth5[m][r] / nth4[m][r]: index of the r-th set bit of a 5-bit / 4-bit mask: the r-th set bit of the
@@ -215,6 +232,29 @@ __device__ inline void fill_nth9(uint8_t *nth9) {
         }
     }
 }
+// the same table as a constant, for kernels that LOAD it (the one-launch-per-step policy kernel requests its words
+// in front of the state loads and stores them to LDS behind them, like the policy table: no compute in front of the
+// workgroup barrier)
+struct Nth9Lut {
+    u32 w[512 * 9 / 4];
+    constexpr Nth9Lut() : w() {
+        for (u32 m = 0; m < 512u; ++m) {
+            uint8_t row[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            u32 r = 0;
+            for (u32 v = 0; v < 9; ++v) {                  // the same fill as fill_nth9: entries past the population
+                row[r] = (uint8_t)v;                       // hold whatever the last rejected square left there
+                r += m >> v & 1u;
+            }
+            for (u32 k = 0; k < 9; ++k) {
+                const u32 byte = m * 9u + k;
+                w[byte >> 2] |= (u32)row[k] << (8u * (byte & 3u));
+            }
+        }
+    }
+};
+__device__ const Nth9Lut g_nth9_lut = Nth9Lut();
+constexpr u32 NTH9_WORDS = 512 * 9 / 4;
+
 // the policy's action for the empty-square mask `empty` (>= 2 squares) from hash word h2: lo | hi << 8
 __device__ __forceinline__ u32 policy_action_nth9(const uint8_t *plut, const uint8_t *nth9, u32 empty, u32 h2) {
     const u32 e = (u32)__builtin_popcount(empty);

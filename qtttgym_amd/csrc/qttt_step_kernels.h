@@ -40,6 +40,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     constexpr u32 TILE_BOARDS = BLOCK * BPL;
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
+    // the full "r-th empty square" table of the fused stepper (4.5 KB) where a workgroup has enough boards to pay for
+    // its load: everything but one board per lane in 256-thread workgroups (the launch-bound shapes)
+    constexpr bool NTH9 = SAMPLE && BLOCK * BPL >= 512;
+    constexpr int N9W = NTH9 ? (int)((NTH9_WORDS + BLOCK - 1) / BLOCK) : 1;
+    __shared__ __attribute__((aligned(16))) u32 nth9w[NTH9 ? NTH9_WORDS : 1];
     __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
     __shared__ __attribute__((aligned(16))) u32 olut[OBS ? OBS_LUT_BYTES / 4 : 4];
 #ifdef QTTT_DEBUG_STAMPS
@@ -68,6 +73,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     u32 plw = 0, olw = 0;
     if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) plw = reinterpret_cast<const u32 *>(&g_policy_lut)[threadIdx.x];
     if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olw = (&g_obs_lut.sel[0][0])[threadIdx.x];
+    u32 n9[N9W];
+    if (NTH9) {
+#pragma unroll
+        for (int k = 0; k < N9W; ++k) {
+            const u32 w = threadIdx.x + (u32)k * BLOCK;
+            n9[k] = w < NTH9_WORDS ? g_nth9_lut.w[w] : 0u;
+        }
+    }
     V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
     V64 q = load_stream(&reinterpret_cast<const V64 *>(pQ + ib)[g]);
     V16 act;
@@ -77,6 +90,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     fill_line_lut_nosync<BLOCK>(lut);
     if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) reinterpret_cast<u32 *>(plut)[threadIdx.x] = plw;
     if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olut[threadIdx.x] = olw;
+    if (NTH9) {
+#pragma unroll
+        for (int k = 0; k < N9W; ++k) {
+            const u32 w = threadIdx.x + (u32)k * BLOCK;
+            if (w < NTH9_WORDS) nth9w[w] = n9[k];
+        }
+    }
     ObsTiles T;
     if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
     __syncthreads();
@@ -92,21 +112,35 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
         for (int k = 0; k < BPL; ++k) {
             u32 P0 = (u32)p.v[k], P1 = (u32)(p.v[k] >> 32);
             u32 Q0 = (u32)q.v[k], Q1 = (u32)(q.v[k] >> 32);
-            u32 bit, av;
+            u32 bit, av, win;
             if (SAMPLE) {
-                // the policy sees the board the step will act on: a finished board counts as empty
                 const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
                 const u32 h2 = lowbias32(h1 ^ key_hi);
-                const u32 empty = policy_empty_mask<AUTO_RESET>(P1);
-                av = (empty & (empty - 1u)) ? policy_action(plut, empty, h2) : 0u;
-                act.v[k] = (uint16_t)av;
+                const uint8_t *nth9 = reinterpret_cast<const uint8_t *>(nth9w);
                 bit = h1 >> 31;
+                if (AUTO_RESET) {
+                    // a finished board restarts first (empty = all zero); a board that is not done has >= 2 empty
+                    // squares (8 classical squares set the done bit), so the policy always finds a legal pair,
+                    // lo < hi by construction: the step runs TRUSTED (no validation, no sorting), as in
+                    // step_random_fused_kernel
+                    const u32 keep = ~(u32)((int)P1 >> 31);
+                    P0 &= keep; P1 &= keep; Q0 &= keep; Q1 &= keep;
+                    const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
+                    av = NTH9 ? policy_action_nth9(plut, nth9, empty, h2) : policy_action(plut, empty, h2);
+                    win = step_core<false, true>(P0, P1, Q0, Q1, av, bit, lut);
+                } else {
+                    // post-terminal legal moves are accepted; no legal pair -> (0,0), a noop
+                    const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
+                    av = (empty & (empty - 1u)) ? (NTH9 ? policy_action_nth9(plut, nth9, empty, h2) : policy_action(plut, empty, h2)) : 0u;
+                    win = step_core<false>(P0, P1, Q0, Q1, av, bit, lut);
+                }
+                act.v[k] = (uint16_t)av;
             } else {
                 av = act.v[k];
                 if (HAS_BITS) bit = bt.v[k] & 1u;
                 else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+                win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
             }
-            const u32 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
             p.v[k] = (u64)P0 | ((u64)P1 << 32);
             q.v[k] = (u64)Q0 | ((u64)Q1 << 32);
             rw.v[k] = 0x80000000u | (win << 23);                         // env.py:49: -1.0f / -0.0f

@@ -461,63 +461,115 @@ class VecEnv:
                                  auto_reset=self.auto_reset if auto_reset is None else auto_reset,
                                  board_offset=self.board_offset if board_offset is None else board_offset)
 
-    def node_info(self, out=None):
+    def node_info(self, out=None, python_key=True):
         """GameState bookkeeping per board (mcts.py:20-27,52-65,93-94): winner i8 (1/0/-1 = True/
-        False/None), terminal bool, legal int64 (bit a = action a legal), key int64 (= Python's
-        hash(tuple(board)+tuple(moves))).  `out` = the dict of an earlier call, to be overwritten."""
+        False/None), terminal bool, legal int64 (bit a = action a legal), state_key int64 (the native 64-bit
+        position key: equal <=> equal (board, moves); qttt_state_key of the packed words) and — with
+        python_key — key int64 = Python's hash(tuple(board)+tuple(moves)), for host-side dicts built by
+        reference code (three quarters of the kernel's work: a device-side search passes python_key=False).
+        `out` = the dict of an earlier call, to be overwritten (its "key" entry decides python_key)."""
         n, dev = self.num_envs, self.device
+        spec = (("winner", torch.int8), ("terminal", torch.bool), ("legal", torch.int64), ("state_key", torch.int64))
         if out is None:
             with torch.cuda.device(dev):
-                out = {"winner": torch.empty(n, dtype=torch.int8, device=dev),
-                       "terminal": torch.empty(n, dtype=torch.bool, device=dev),
-                       "legal": torch.empty(n, dtype=torch.int64, device=dev),
-                       "key": torch.empty(n, dtype=torch.int64, device=dev)}
+                out = {k: torch.empty(n, dtype=dt, device=dev) for k, dt in spec}
+                if python_key:
+                    out["key"] = torch.empty(n, dtype=torch.int64, device=dev)
         else:
-            for k, dt in (("winner", torch.int8), ("terminal", torch.bool), ("legal", torch.int64), ("key", torch.int64)):
+            for k, dt in spec + ((("key", torch.int64),) if "key" in out else ()):
                 t = out[k]
                 if t.dtype != dt or t.numel() != n or not t.is_contiguous() or t.device != self.state.device:
                     raise ValueError("out[%r] must be a contiguous %s device tensor of N elements" % (k, dt))
         rc = self._launch(self._lib.qttt_node_info, self.state.data_ptr(), out["winner"].data_ptr(),
-                          out["terminal"].data_ptr(), out["legal"].data_ptr(), out["key"].data_ptr(), n,
+                          out["terminal"].data_ptr(), out["legal"].data_ptr(), _ptr(out.get("key")),
+                          out["state_key"].data_ptr(), n, self._stream())
+        _native.check(rc, "qttt_node_info")
+        return out
+
+    def state_keys(self, out=None):
+        """The native position keys alone (int64[N]): 16 bytes read and 8 written per board."""
+        n = self.num_envs
+        if out is None:
+            with torch.cuda.device(self.device):
+                out = torch.empty(n, dtype=torch.int64, device=self.device)
+        else:
+            _check_out(out, torch.int64, (n,), self.state.device, "out")
+        rc = self._launch(self._lib.qttt_node_info, self.state.data_ptr(), None, None, None, None, out.data_ptr(), n,
                           self._stream())
         _native.check(rc, "qttt_node_info")
         return out
 
-    def expand(self, action36, out=None):
-        """MCTS._step (mcts.py:233-267) for every board: action36 u8[N] (ind2move index).
-        Returns dict(child0, child1 = VecEnv over the child states, n_children u8[N],
-        winner i8[N,2], terminal bool[N,2], legal int64[N,2], key int64[N,2]).
-        `out` = the dict of an earlier call: its child states and tensors are overwritten (a search loop
-        then allocates nothing per expansion)."""
+    _EXPAND_ROWS = (("n_children", torch.uint8, ()), ("winner", torch.int8, (2,)), ("terminal", torch.bool, (2,)),
+                    ("legal", torch.int64, (2,)), ("state_key", torch.int64, (2,)))
+
+    def _expand_out(self, out, python_key, extra=()):
+        """The output dict of expand / expand_rollout: allocated, or the one of an earlier call checked."""
         n, dev = self.num_envs, self.device
-        a = action36
-        if not (torch.is_tensor(a) and a.dtype == torch.uint8 and a.device == self.state.device and a.is_contiguous()):
-            a = torch.as_tensor(a).to(torch.uint8).to(dev).contiguous()
-        if a.shape != (n,):
-            raise ValueError("action36 must have shape (%d,)" % n)
         if out is None:
             with torch.cuda.device(dev):
                 mk = lambda: VecEnv.from_state(torch.empty_like(self.state), n, seed=self.seed, board_offset=self.board_offset)
-                out = {"child0": mk(), "child1": mk(),
-                       "n_children": torch.empty(n, dtype=torch.uint8, device=dev),
-                       "winner": torch.empty((n, 2), dtype=torch.int8, device=dev),
-                       "terminal": torch.empty((n, 2), dtype=torch.bool, device=dev),
-                       "legal": torch.empty((n, 2), dtype=torch.int64, device=dev),
-                       "key": torch.empty((n, 2), dtype=torch.int64, device=dev)}
+                out = {"child0": mk(), "child1": mk()}
+                for k, dt, shp in self._EXPAND_ROWS + tuple(extra):
+                    out[k] = torch.empty((n,) + shp, dtype=dt, device=dev)
+                if python_key:
+                    out["key"] = torch.empty((n, 2), dtype=torch.int64, device=dev)
         else:
             sd = self.state.device
             for c in ("child0", "child1"):
                 if out[c].num_envs != n or out[c].state.device != sd:
                     raise ValueError("out[%r] must be a VecEnv of N boards on this device" % c)
-            _check_out(out["n_children"], torch.uint8, (n,), sd, "out['n_children']")
-            _check_out(out["winner"], torch.int8, (n, 2), sd, "out['winner']")
-            _check_out(out["terminal"], torch.bool, (n, 2), sd, "out['terminal']")
-            _check_out(out["legal"], torch.int64, (n, 2), sd, "out['legal']")
-            _check_out(out["key"], torch.int64, (n, 2), sd, "out['key']")
+            for k, dt, shp in self._EXPAND_ROWS + tuple(extra) + ((("key", torch.int64, (2,)),) if "key" in out else ()):
+                _check_out(out[k], dt, (n,) + shp, sd, "out[%r]" % k)
+        return out
+
+    def _as_action36(self, action36):
+        a = action36
+        if not (torch.is_tensor(a) and a.dtype == torch.uint8 and a.device == self.state.device and a.is_contiguous()):
+            a = torch.as_tensor(a).to(torch.uint8).to(self.device).contiguous()
+        if a.shape != (self.num_envs,):
+            raise ValueError("action36 must have shape (%d,)" % self.num_envs)
+        return a
+
+    def expand(self, action36, out=None, python_key=True):
+        """MCTS._step (mcts.py:233-267) for every board: action36 u8[N] (ind2move index).
+        Returns dict(child0, child1 = VecEnv over the child states, n_children u8[N],
+        winner i8[N,2], terminal bool[N,2], legal int64[N,2], state_key int64[N,2] and — with python_key —
+        key int64[N,2] = Python's hash of each child, see node_info).
+        `out` = the dict of an earlier call: its child states and tensors are overwritten (a search loop
+        then allocates nothing per expansion); its "key" entry decides python_key."""
+        n = self.num_envs
+        a = self._as_action36(action36)
+        out = self._expand_out(out, python_key)
         rc = self._launch(self._lib.qttt_expand, self.state.data_ptr(), a.data_ptr(), out["child0"].state.data_ptr(),
                           out["child1"].state.data_ptr(), out["n_children"].data_ptr(), out["winner"].data_ptr(),
-                          out["terminal"].data_ptr(), out["legal"].data_ptr(), out["key"].data_ptr(), n, self._stream())
+                          out["terminal"].data_ptr(), out["legal"].data_ptr(), _ptr(out.get("key")),
+                          out["state_key"].data_ptr(), n, self._stream())
         _native.check(rc, "qttt_expand")
+        return out
+
+    def expand_rollout(self, action36, n_sims=1, step_idx0=None, out=None, python_key=False, with_result=False):
+        """One MCTS._rollout below the selected node in ONE launch (mcts.py:166-176,210-221,233-267): expand() plus
+        n_sims random playouts from EACH child.  Returns expand()'s dict with two more entries:
+        value_sum int32[N,2] = the sum over a child's playouts of `r if leaf.turn else -r` (mcts.py:174; divide by
+        n_sims for the value _backpropogate receives) and — with_result — result int8[N,2,n_sims], every playout's
+        MCTS._reward.  Bit-identical to expand() followed by child0.rollout_many(n_sims, step_idx0) and
+        child1.rollout_many(n_sims, step_idx0 + 16 * n_sims).  `out` = the dict of an earlier call with the same
+        n_sims, overwritten."""
+        n, S = self.num_envs, int(n_sims)
+        if not 1 <= S <= _native.EXPAND_ROLLOUT_MAX_SIMS:
+            raise ValueError("n_sims must be in 1..%d" % _native.EXPAND_ROLLOUT_MAX_SIMS)
+        if step_idx0 is None:
+            step_idx0 = self.step_idx
+        a = self._as_action36(action36)
+        with_result = with_result or (out is not None and "result" in out)
+        extra = (("value_sum", torch.int32, (2,)),) + ((("result", torch.int8, (2, S)),) if with_result else ())
+        out = self._expand_out(out, python_key, extra)
+        rc = self._launch(self._lib.qttt_expand_rollout, self.state.data_ptr(), a.data_ptr(),
+                          out["child0"].state.data_ptr(), out["child1"].state.data_ptr(), out["n_children"].data_ptr(),
+                          out["winner"].data_ptr(), out["terminal"].data_ptr(), out["legal"].data_ptr(),
+                          _ptr(out.get("key")), out["state_key"].data_ptr(), self.seed, int(step_idx0), self.board_offset,
+                          S, out["value_sum"].data_ptr(), _ptr(out.get("result")), n, self._stream())
+        _native.check(rc, "qttt_expand_rollout")
         return out
 
     def rollout(self, step_idx0=None, return_final=False, out=None):

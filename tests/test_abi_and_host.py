@@ -62,7 +62,14 @@ def test_env_record_call_validates_before_touching_the_device():
     assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, None, -1, 4, None) == -2
     assert L.qttt_step_random_many(None, 0, 0, 0, 0, None, None, None, 0, None, 8, 0, None) == 0             # no steps: nothing to do
     assert L.qttt_export(None, None, None, None, None, None, 8, None) == -1
-    assert L.qttt_node_info(None, None, None, None, None, 8, None) == -1
+    assert L.qttt_node_info(None, None, None, None, None, None, 8, None) == -1
+    assert L.qttt_expand(None, None, None, None, None, None, None, None, None, None, 8, None) == -1
+    assert L.qttt_expand_rollout(None, None, None, None, None, None, None, None, None, None, 0, 0, 0, 1, None, None, 8, None) == -1
+    assert L.qttt_expand_rollout(None, None, None, None, None, None, None, None, None, None, 0, 0, 0, 0, None, None, 8, None) == -2
+    assert L.qttt_expand_rollout(None, None, None, None, None, None, None, None, None, None, 0, 0, 0, 129, None, None, 8, None) == -2
+    # the native position key is host-callable: the empty board's key is the mix of two zero words
+    assert L.qttt_state_key(0, 0) == 0 and L.qttt_state_key(1 << 40, 0) != 0
+    assert L.qttt_state_key(1 << 40, 5) == L.qttt_state_key((1 << 40) | (1 << 63) | (0xF << 44), 5 | (0x1FF << 32))
     assert L.qttt_export(None, None, None, None, None, None, 0, None) == 0
 
 

@@ -289,12 +289,15 @@ def test_expand_wants_aligned_rows():
     tm = torch.empty(2 * n + 8, dtype=torch.uint8, device="cuda")
     lg = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
     ky = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
-    ok = lambda wp, tp, lp, kp: L.qttt_expand(env.state.data_ptr(), a.data_ptr(), c0.data_ptr(), c1.data_ptr(), nch.data_ptr(),
-                                              wp, tp, lp, kp, n, s)
+    sk = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
+    ok = lambda wp, tp, lp, kp, sp=sk.data_ptr(): L.qttt_expand(env.state.data_ptr(), a.data_ptr(), c0.data_ptr(), c1.data_ptr(),
+                                                                nch.data_ptr(), wp, tp, lp, kp, sp, n, s)
     assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr()) == 0
     assert ok(w.data_ptr() + 1, tm.data_ptr(), lg.data_ptr(), ky.data_ptr()) == -3
     assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr() + 8, ky.data_ptr()) == -3
     assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr() + 8) == -3
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr(), sk.data_ptr() + 8) == -3
+    assert ok(None, None, None, None, None) == 0                      # every per-child row is nullable
 
 
 def test_rollout_and_encode_out_reuse():

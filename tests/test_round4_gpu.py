@@ -1,0 +1,319 @@
+"""Round 4 on the GPU (through the C ABI):
+  * the playout loop against the fixture recorded from the reference's own MCTS._rollout / _simulate / _reward
+    (tests/golden/playout_traces.npz, make_golden_playout.py): qttt_rollout, qttt_rollout_many, qttt_expand_rollout;
+  * the packed state is a canonical form of (board, moves): qttt_import(qttt_export(s)) == s bit for bit at every
+    depth, and the native position key is equal exactly where CPython's hash of (board, moves) is;
+  * qttt_expand_rollout == qttt_expand followed by qttt_rollout_many on each child;
+  * the policy-in-the-step kernel (nth9 table + trusted step) == policy kernel + step kernel in every launch shape;
+  * the Board façade mutates its attributes in place, as the reference does.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _load(name):
+    with np.load(os.path.join(ROOT, "tests", "golden", name)) as d:
+        return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="module")
+def gp():
+    return _load("playout_traces.npz")
+
+
+@pytest.fixture(scope="module")
+def gx():
+    return _load("expand_traces.npz")
+
+
+def env_from(board, moves, n_moves, qmask, n_q, **kw):
+    from qtttgym_amd import VecEnv
+    env = VecEnv(len(n_moves), **kw)
+    env.import_boards(torch.from_numpy(moves.copy()), torch.from_numpy(n_moves.copy()),
+                      torch.from_numpy(board.copy()), torch.from_numpy(qmask.view(np.int16).copy()),
+                      torch.from_numpy(n_q.copy()))
+    return env
+
+
+def playout_groups(gp):
+    start = 0
+    for g in range(len(gp["g_seed"])):
+        n = int(gp["g_count"][g])
+        yield int(gp["g_seed"][g]), int(gp["g_offset"][g]), int(gp["g_step_idx0"][g]), slice(start, start + n)
+        start += n
+
+
+# ---------------------------------------------------------------------------------------- the playout loop
+def test_rollout_reproduces_the_reference_simulate_loop(gp):
+    """MCTS._simulate / _reward / the num_simulations loop (mcts.py:166-176,185-209) as the reference ran them, its
+    random sources keyed by the counter hash: result, plies played (termination, the nine-ply cap) and the end
+    state of every simulation, through qttt_rollout and qttt_rollout_many."""
+    S, stride = int(gp["n_sims"]), int(gp["sim_stride"])
+    from qtttgym_amd import _native
+    assert stride == _native.SIM_STRIDE
+    for seed, offset, step0, sl in playout_groups(gp):
+        env = env_from(gp["p_board"][sl], gp["p_moves"][sl], gp["p_n_moves"][sl], gp["p_qmask"][sl], gp["p_n_q"][sl],
+                       seed=seed, board_offset=offset)
+        info = env.node_info()
+        assert np.array_equal(_np(info["winner"]), gp["p_winner"][sl])
+        assert np.array_equal(_np(info["terminal"]), gp["p_terminal"][sl])
+        many, many_pl = env.rollout_many(S, step_idx0=step0, with_plies=True)
+        assert np.array_equal(_np(many), gp["s_result"][sl])
+        assert np.array_equal(_np(many_pl), gp["s_plies"][sl])
+        for s in range(S):
+            result, plies, final = env.rollout(step_idx0=step0 + s * stride, return_final=True)
+            assert np.array_equal(_np(result), gp["s_result"][sl, s])
+            assert np.array_equal(_np(plies), gp["s_plies"][sl, s])
+            ex = {k: _np(v) for k, v in final.export_boards().items()}
+            assert np.array_equal(ex["board"], gp["s_f_board"][sl, s])
+            assert np.array_equal(ex["moves"], gp["s_f_moves"][sl, s])
+            assert np.array_equal(ex["n_moves"], gp["s_f_n_moves"][sl, s])
+            assert np.array_equal(_np(final.node_info(python_key=False)["winner"]), gp["s_f_winner"][sl, s])
+        # the value MCTS._rollout hands to _backpropogate: r_tot / num_simulations, r_tot += r if leaf.turn else -r
+        sign = np.where(gp["p_turn"][sl], 1, -1)
+        assert np.array_equal(sign * _np(many).astype(np.int64).sum(1) / float(S), gp["p_value"][sl])
+
+
+def test_expand_rollout_children_against_the_oracle_playout_loop(gp):
+    """qttt_expand_rollout on the fixture's parents: every child's every simulation against the oracle's playout
+    loop (which the CPU suite pins to the reference's recording), value_sum with the leaf.turn sign."""
+    S = 3
+    rng = np.random.default_rng(5)
+    for seed, offset, step0, sl in playout_groups(gp):
+        n = sl.stop - sl.start
+        env = env_from(gp["p_board"][sl], gp["p_moves"][sl], gp["p_n_moves"][sl], gp["p_qmask"][sl], gp["p_n_q"][sl],
+                       seed=seed, board_offset=offset)
+        ob = oracle.boards_from_arrays(gp["p_board"][sl], gp["p_moves"][sl], gp["p_n_moves"][sl], gp["p_qmask"][sl], gp["p_n_q"][sl])
+        act = rng.integers(0, 36, n).astype(np.uint8)
+        out = env.expand_rollout(torch.from_numpy(act), n_sims=S, step_idx0=step0, with_result=True, python_key=True)
+        nch, kids, winner, terminal, legal, key = oracle.expand(ob, act)
+        assert np.array_equal(_np(out["n_children"]), nch) and (nch == 2).sum() > 50
+        res = _np(out["result"])
+        vs = _np(out["value_sum"])
+        for c in range(2):
+            sel = nch > c
+            assert np.array_equal(_np(out["key"])[sel, c], key[sel, c])
+            assert np.array_equal(_np(out["winner"])[sel, c], winner[sel, c])
+            total = np.zeros(n, dtype=np.int64)
+            for s in range(S):
+                r_o, _, _ = oracle.rollout(kids[c], seed, step0 + (c * S + s) * 16, offset)
+                assert np.array_equal(res[sel, c, s], r_o[sel]), (c, s)
+                total += r_o
+            assert (res[~sel, c] == 0).all()
+            # leaf.turn (mcts.py:174,243): the parent's turn flipped by the move
+            child_turn = ~gp["p_turn"][sl]
+            assert np.array_equal(vs[sel, c], np.where(child_turn, total, -total)[sel])
+            assert (vs[~sel, c] == 0).all()
+
+
+@pytest.mark.parametrize("n,sims", [(1, 1), (5, 3), (1000, 10), (65536, 1), (65536, 10), (4099, 33), (300, 128)])
+def test_expand_rollout_equals_expand_then_rollout_many(n, sims):
+    """One launch == qttt_expand + qttt_rollout_many(child0, step_idx0) + qttt_rollout_many(child1, step_idx0 + 16 n_sims)."""
+    from qtttgym_amd import VecEnv
+    env = VecEnv(n, seed=31, board_offset=7 * n)
+    rng = np.random.default_rng(n + sims)
+    depth = torch.from_numpy(rng.integers(0, 9, n).astype(np.uint8)).cuda()
+    for t in range(8):                                                  # parents at mixed depths (some finished)
+        a = env.sample_actions()
+        a[depth <= t] = 0
+        env.step_raw(a)
+    act = torch.from_numpy(rng.integers(0, 40, n).astype(np.uint8)).cuda()      # a few non-actions (36..39)
+    s0 = 77
+    one = env.expand_rollout(act, n_sims=sims, step_idx0=s0, with_result=True, python_key=True)
+    ex = env.expand(act)
+    for k in ("n_children", "winner", "terminal", "legal", "key", "state_key"):
+        assert torch.equal(one[k], ex[k]), k
+    assert torch.equal(one["child0"].state, ex["child0"].state) and torch.equal(one["child1"].state, ex["child1"].state)
+    nch = ex["n_children"]
+    r0 = ex["child0"].rollout_many(sims, step_idx0=s0)
+    r1 = ex["child1"].rollout_many(sims, step_idx0=s0 + 16 * sims)
+    r0 = torch.where((nch >= 1)[:, None], r0, torch.zeros_like(r0))
+    r1 = torch.where((nch >= 2)[:, None], r1, torch.zeros_like(r1))
+    assert torch.equal(one["result"][:, 0], r0) and torch.equal(one["result"][:, 1], r1)
+    # leaf.turn: True after an even number of real moves (the autofill move is not one)
+    for c, (child, r) in enumerate(((ex["child0"], r0), (ex["child1"], r1))):
+        exb = child.export_boards()
+        mv, nm = exb["moves"], exb["n_moves"].to(torch.int64)
+        last = mv[torch.arange(n, device=mv.device), (nm - 1).clamp(min=0)]
+        real = nm - ((nm > 0) & (last[:, 0] == last[:, 1])).to(torch.int64)
+        sign = torch.where(real % 2 == 0, 1, -1).to(torch.int32)
+        assert torch.equal(one["value_sum"][:, c], sign * r.to(torch.int32).sum(1)), c
+    # out= reuse, without the per-simulation results and without the CPython keys
+    lean = env.expand_rollout(act, n_sims=sims, step_idx0=s0)
+    assert "result" not in lean and "key" not in lean and torch.equal(lean["value_sum"], one["value_sum"])
+    lean["value_sum"].zero_()
+    assert env.expand_rollout(act, n_sims=sims, step_idx0=s0, out=lean) is lean
+    assert torch.equal(lean["value_sum"], one["value_sum"]) and torch.equal(lean["state_key"], one["state_key"])
+    with pytest.raises(ValueError):
+        env.expand_rollout(act, n_sims=0)
+    with pytest.raises(ValueError):
+        env.expand_rollout(act, n_sims=129)
+    # children are optional at the C ABI (a search that keeps keys and values only)
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    v2 = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    assert L.qttt_expand_rollout(env.state.data_ptr(), act.data_ptr(), None, None, None, None, None, None, None, None,
+                                 env.seed, s0, env.board_offset, sims, v2.data_ptr(), None, n, s) == 0
+    assert torch.equal(v2, one["value_sum"])
+
+
+# ---------------------------------------------------------------------------------------- canonical state, native key
+def _mixed_depth_env(n, seed, auto_reset=False, plies=9, rng_seed=0, explicit_bits=False):
+    from qtttgym_amd import VecEnv
+    env = VecEnv(n, seed=seed, auto_reset=auto_reset)
+    rng = np.random.default_rng(rng_seed)
+    depth = torch.from_numpy(rng.integers(0, 10, n).astype(np.uint8)).cuda()
+    for t in range(plies):
+        a = env.sample_actions()
+        if not auto_reset:
+            a[depth <= t] = 255                                         # frozen boards get a noop
+        bits = torch.from_numpy(rng.integers(0, 2, n).astype(np.uint8)).cuda() if explicit_bits else None
+        env.step_raw(a, bits)
+    return env
+
+
+@pytest.mark.parametrize("n,auto_reset,plies,bits", [(64 * 300, False, 9, False), (10007, False, 9, True),
+                                                     (1 << 20, False, 9, False), (50000, True, 40, False)])
+def test_import_of_export_is_the_state_bit_for_bit(n, auto_reset, plies, bits):
+    """The packed 16 bytes are a canonical form of the Board attributes: stepped boards at every depth (finished
+    games, the implicit autofill, nine real moves included), exported and imported into a fresh environment, give
+    the same two words per board — the rooted forest included (qttt_import re-plays the un-collapsed moves with
+    the step's own choice of the child end)."""
+    from qtttgym_amd import VecEnv
+    env = _mixed_depth_env(n, 41, auto_reset, plies, rng_seed=n, explicit_bits=bits)
+    ex = env.export_boards()
+    if not auto_reset:
+        nm = _np(ex["n_moves"])
+        assert (nm == 9).sum() > n // 50 and (nm == 0).sum() > n // 50
+    back = VecEnv(n)
+    back.import_boards(ex["moves"], ex["n_moves"], ex["board"], ex["qmask"], ex["n_q"])
+    a, b = env.state.view(torch.int64).view(2, -1)[:, :n], back.state.view(torch.int64).view(2, -1)[:, :n]
+    bad = ((a != b).any(0)).nonzero().flatten()
+    assert bad.numel() == 0, "boards %s: stepped %s imported %s" % (
+        bad[:4].tolist(), [hex(int(x) & (2**64 - 1)) for x in a[:, bad[0]]], [hex(int(x) & (2**64 - 1)) for x in b[:, bad[0]]])
+    assert torch.equal(env.state_keys(), back.state_keys())
+
+
+def test_native_key_partitions_like_the_python_hash_on_the_reference_children(gx):
+    """expand_traces.npz: parents and all children the reference's own mcts.py produced (c_hash = Python's hash of
+    each).  Native keys are equal exactly where the reference's hashes are; the kernel's key is qttt_state_key of the
+    two packed words; the child keys of qttt_expand are the keys of the child states."""
+    idx = gx["parent"]
+    env = env_from(gx["p_board"][idx], gx["p_moves"][idx], gx["p_n_moves"][idx], gx["p_qmask"][idx], gx["p_n_q"][idx])
+    out = env.expand(torch.from_numpy(gx["action"].copy()))
+    nch = _np(out["n_children"])
+    py, nat = [gx["p_hash"][idx]], [_np(env.state_keys())]
+    for c, child in enumerate((out["child0"], out["child1"])):
+        sel = nch > c
+        assert np.array_equal(_np(out["key"])[sel, c], gx["c_hash"][sel, c])
+        info = child.node_info()
+        assert np.array_equal(_np(info["state_key"])[sel], _np(out["state_key"])[sel, c])
+        assert np.array_equal(_np(info["key"])[sel], gx["c_hash"][sel, c])
+        assert (_np(out["state_key"])[~sel, c] == 0).all()
+        # children built from the reference's attributes (import) get the key of the children built by stepping
+        imp = env_from(gx["c_board"][:, c], gx["c_moves"][:, c], gx["c_n_moves"][:, c], gx["c_qmask"][:, c], gx["c_n_q"][:, c])
+        assert np.array_equal(_np(imp.state_keys())[sel], _np(out["state_key"])[sel, c])
+        py.append(gx["c_hash"][sel, c])
+        nat.append(_np(out["state_key"])[sel, c])
+    py, nat = np.concatenate(py), np.concatenate(nat)
+    pairs = np.unique(np.stack([py, nat], 1), axis=0)
+    assert len(pairs) == len(np.unique(py)) == len(np.unique(nat))         # a bijection between the two key sets
+    assert len(np.unique(py)) > 3000
+    # the kernel's key is the host-callable mix of the packed words
+    L = env._lib
+    planes = _np(out["child0"].state.view(torch.int64).view(2, -1)).view(np.uint64)
+    for i in range(0, len(idx), 97):
+        assert L.qttt_state_key(int(planes[0, i]), int(planes[1, i])) == int(_np(out["state_key"]).view(np.uint64)[i, 0]) or nch[i] == 0
+
+
+def test_native_key_equal_iff_python_key_equal_on_a_million_boards():
+    """1 048 576 boards at mixed depths (many repeated positions early in the game, finished games late): the pairs
+    (CPython key, native key) are a bijection, and qstructs handed over in another list order or a stale done bit
+    do not change the key."""
+    n = 1 << 20
+    env = _mixed_depth_env(n, 3, plies=9, rng_seed=8)
+    info = env.node_info()
+    py, nat = info["key"], info["state_key"]
+    n_py, n_nat = torch.unique(py).numel(), torch.unique(nat).numel()
+    n_pair = torch.unique(torch.stack([py, nat], 1), dim=0).shape[0]
+    assert n_py == n_nat == n_pair and n_py > 200000, (n_py, n_nat, n_pair)
+    assert torch.equal(env.state_keys(), nat)
+    # the same positions with the qstructs listed in reverse order: same keys, different packed words
+    ex = env.export_boards()
+    nq = ex["n_q"].to(torch.int64)
+    k = torch.arange(4, device="cuda")[None, :]
+    rev = torch.where(k < nq[:, None], (nq[:, None] - 1 - k).clamp(min=0), k)
+    from qtttgym_amd import VecEnv
+    other = VecEnv(n)
+    other.import_boards(ex["moves"], ex["n_moves"], ex["board"], torch.gather(ex["qmask"], 1, rev), ex["n_q"])
+    assert not torch.equal(other.state, env.state)
+    assert torch.equal(other.state_keys(), nat)
+
+
+# ---------------------------------------------------------------------------------------- policy in the step kernel
+@pytest.mark.parametrize("n", [4096, 500 * 1024, 600 * 1024 + 3, 1 << 20, (1 << 21) + 64])
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_step_random_equals_policy_kernel_plus_step_in_every_shape(n, auto_reset):
+    """qttt_step_random (policy through the full n-th-empty-square table, trusted step under auto-reset) against
+    qttt_sample_actions + qttt_step, in each region of the launch-shape table."""
+    from qtttgym_amd import VecEnv
+    a_env = VecEnv(n, seed=77, auto_reset=auto_reset, board_offset=(1 << 32) - n // 2)   # ids cross 2^32
+    b_env = VecEnv(n, seed=77, auto_reset=auto_reset, board_offset=(1 << 32) - n // 2)
+    played = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(12):
+        act = b_env.sample_actions()
+        rb, tb = b_env.step_raw(act)
+        ra, ta = a_env.step_random(actions_out=played)
+        assert torch.equal(played, act), t
+        assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(ta, tb), t
+    assert torch.equal(a_env.state, b_env.state)
+
+
+# ---------------------------------------------------------------------------------------- façade identity
+def test_board_attributes_are_mutated_in_place():
+    """board.py:19,25 append to .moves, :53-54 write into .board, :56-69 pop / assign / append on .qstructs and
+    grow a set with .add: a caller holding the list (or set) objects sees every move."""
+    from qtttgym_amd import Board, QEvalClassic
+
+    class Fixed(QEvalClassic):
+        def choose(self, lo, hi):
+            return hi
+
+    b = Board(Fixed())
+    mv, bd, qs = b.moves, b.board, b.qstructs
+    b.make_move((0, 1))
+    assert b.moves is mv and mv == [(0, 1, 0)] and b.qstructs is qs and qs == [{0, 1}] and b.board is bd
+    s0 = qs[0]
+    b.make_move((2, 1))
+    assert mv == [(0, 1, 0), (1, 2, 1)] and qs[0] is s0 and s0 == {0, 1, 2}          # board.py:68-69: grown in place
+    b.make_move((3, 4))
+    s1 = qs[1]
+    assert qs[0] is s0 and s1 == {3, 4}
+    b.make_move((5, 6))
+    s2 = qs[2]
+    b.make_move((2, 3))                                                              # board.py:58-61: union, a new set
+    assert b.qstructs is qs and qs == [{0, 1, 2, 3, 4}, {5, 6}] and qs[1] is s2 and qs[0] is not s0
+    b.make_move((0, 4))                                                              # closes a cycle: the component goes
+    assert b.qstructs is qs and qs == [{5, 6}] and qs[0] is s2
+    assert b.board is bd and bd == [0, 1, 4, 2, 5, -1, -1, -1, -1] and b.moves is mv and len(mv) == 6
+    with pytest.raises(Exception):
+        b.make_move((0, 5))
+    assert len(mv) == 6
+    # update_qstructs on its own (the caller appended the move, board.py:19-20) and make_moves keep identity too
+    b.moves.append((7, 8, len(b.moves)))
+    b.update_qstructs((7, 8))
+    assert b.moves is mv and len(mv) == 7 and qs == [{5, 6}, {7, 8}] and qs[0] is s2
+    c = Board(Fixed())
+    cm, cq = c.moves, c.qstructs
+    assert Board.make_moves([c], [(4, 8)]) == [None] and c.moves is cm and cm == [(4, 8, 0)] and c.qstructs is cq

@@ -46,10 +46,13 @@ def main():
     tm = torch.empty((n, 2), dtype=torch.bool, device="cuda")
     lg = torch.empty((n, 2), dtype=torch.int64, device="cuda")
     ky = torch.empty((n, 2), dtype=torch.int64, device="cuda")
+    sk = torch.empty((n, 2), dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     t = timed(lambda: L.qttt_expand(st.data_ptr(), act.data_ptr(), c0.data_ptr(), c1.data_ptr(), nch.data_ptr(),
-                                    w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr(), n, s))
-    out.append({"row": "expand", "boards": n, "us": t * 1e6, "expansions_per_s": n / t,
+                                    w.data_ptr(), tm.data_ptr(), lg.data_ptr(), None, sk.data_ptr(), n, s))
+    t_py = timed(lambda: L.qttt_expand(st.data_ptr(), act.data_ptr(), c0.data_ptr(), c1.data_ptr(), nch.data_ptr(),
+                                       w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr(), sk.data_ptr(), n, s))
+    out.append({"row": "expand", "boards": n, "us": t * 1e6, "us_with_python_keys": t_py * 1e6, "expansions_per_s": n / t,
                 "reference_cpu_step_calls_per_s": 4900})
     for n in (65536, 1 << 20):
         env = midgame(n, 0)
@@ -101,12 +104,17 @@ def main():
     t_out = timed(lambda: env.check_win(out=(p1, p2)), reps=20)
     out.append({"row": "check_win", "boards": n, "us": t * 1e6, "us_out_reuse": t_out * 1e6, "us_kernel_only": t_raw * 1e6,
                 "output_bytes_per_board": 2})
-    t = timed(lambda: env.node_info(), reps=10)
+    t = timed(lambda: env.node_info(python_key=False), reps=10)
     ni = env.node_info()
     t_raw = timed(lambda: env._lib.qttt_node_info(env.state.data_ptr(), ni["winner"].data_ptr(), ni["terminal"].data_ptr(),
-                                                  ni["legal"].data_ptr(), ni["key"].data_ptr(), n, s), reps=20)
-    t_out = timed(lambda: env.node_info(out=ni), reps=20)
+                                                  ni["legal"].data_ptr(), None, ni["state_key"].data_ptr(), n, s), reps=20)
+    t_py = timed(lambda: env._lib.qttt_node_info(env.state.data_ptr(), ni["winner"].data_ptr(), ni["terminal"].data_ptr(),
+                                                 ni["legal"].data_ptr(), ni["key"].data_ptr(), ni["state_key"].data_ptr(), n, s), reps=20)
+    t_key = timed(lambda: env._lib.qttt_node_info(env.state.data_ptr(), None, None, None, None, ni["state_key"].data_ptr(), n, s), reps=20)
+    ni_native = {k: v for k, v in ni.items() if k != "key"}
+    t_out = timed(lambda: env.node_info(out=ni_native), reps=20)
     out.append({"row": "node_info", "boards": n, "us": t * 1e6, "us_out_reuse": t_out * 1e6, "us_kernel_only": t_raw * 1e6,
+                "us_kernel_only_with_python_key": t_py * 1e6, "us_kernel_only_state_key_alone": t_key * 1e6,
                 "output_bytes_per_board": 18})
     # fused replay (QTTT_FLAG_FUSED): T steps per launch, boards in registers
     for n in (4096, 262144, 1 << 20):
