@@ -30,9 +30,19 @@ Legs.  At N = 1 the same JSON object carries `legs`: the other BASELINE configur
 in the same process on the same clock (HIP events, median region) — env.step replay at 4 096 / 262 144 /
 16 777 216 boards (the last cannot live in the 256 MB Infinity Cache), `gym` and `random` at 1 M, the fused
 random-policy multi-step kernel (qttt_step_random_many) at 4 096 / 262 144 / 1 M, BASELINE config 5's
-unit (expand + node_info + rollout on 65 536 boards), and the kernels beside the step one by one at 1 M boards
-(observe, export, turn, check_win, node_info, expand, rollout, encode).  Each with us per launch, algorithmic
-bytes, frac.
+unit (one MCTS rollout below 65 536 selected nodes = qttt_expand_rollout: expand + the children's bookkeeping +
+playouts from each child, ONE launch; the three-launch composition beside it), and the kernels beside the step one
+by one at 1 M boards (observe, export, turn, check_win, node_info with the native / the CPython key, expand with
+either, rollout, encode).  Each with us per launch, algorithmic bytes, frac.
+
+Commands.  The headline (and what the driver's SCALE run measures, WEAK scaling: 1 048 576 boards per GPU, so N
+GPUs are N independent loops and the >= 7x of BASELINE.json holds by construction):
+    python bench.py --gpus N --steps K --warmup W
+BASELINE config 4 as stated (2 097 152 boards over 8 GPUs, STRONG scaling: 262 144 boards per GPU is one partial
+occupancy round per launch, predicted 3.4 - 4.1x launch-per-step and 5.8 - 6.4x fused, DESIGN.md §8 — the >= 7x claim
+does NOT apply to it):
+    python bench.py --gpus 8 --total-boards 2097152 --mode random-fused
+QTTT_BENCH_NO_GATHER=1 skips the optional returns gather (the only collective that moves per-board data).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -51,6 +61,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0   # same guide: what a float4 copy kernel reaches on this part
 PMC_SUMMARY = os.path.join("profiles", "pmc_traffic.json")
 TARGET_TIMED_S = 0.05     # the repeated regions add up to at least this much device time
 MAX_REGIONS = 400
@@ -224,6 +235,43 @@ def median(xs):
     s = sorted(xs)
     m = len(s) // 2
     return s[m] if len(s) & 1 else 0.5 * (s[m - 1] + s[m])
+
+
+def time_calls(torch, dev, fn, K, regions):
+    """us per call of `fn` (a VecEnv method with reused buffers), two ways, both by HIP events on the launch stream:
+    eager — K Python calls per region: below ~6 us per kernel this is the HOST's rate (ctypes + hipLaunchKernel), not
+    the kernel's; graph — the same K launches captured once in a hipGraph and replayed: the device's own back-to-back
+    rate, which is what a roofline fraction may be held against.  Returns (graph us list, eager us list)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eager = []
+    for _ in range(regions):
+        for _ in range(3):
+            fn()
+        e0.record()
+        for _ in range(K):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        eager.append(e0.elapsed_time(e1) * 1e3 / K)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(K):
+                fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    dev_paced = []
+    for _ in range(regions):
+        graph.replay()
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        dev_paced.append(e0.elapsed_time(e1) * 1e3 / K)
+    return dev_paced, eager
 
 
 # ---------------------------------------------------------------------------- one workload, one clock
@@ -402,8 +450,9 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
         env.step_raw(env.sample_actions())
     sb = env.state.numel() // ((n + 63) // 64 * 64)
     act = torch.randint(0, 36, (n,), dtype=torch.uint8, device=dev)
-    obs, ex, ni, cw, tn = env.observ(), env.export_boards(), env.node_info(), env.check_win(), env.turn()
-    xp, ro, enc = env.expand(act), env.rollout(), env.encode()
+    obs, ex, ni, cw, tn = env.observ(), env.export_boards(), env.node_info(python_key=False), env.check_win(), env.turn()
+    ni_py, sk = env.node_info(python_key=True), env.state_keys()
+    xp, xp_py, ro, enc = env.expand(act, python_key=False), env.expand(act, python_key=True), env.rollout(), env.encode()
     env_in = VecEnv(n, device=dev, seed=args.seed)             # the target of the import row
     rows = [
         ("observe", "observe_kernel", lambda: env.observ(), sb + 30, "hbm"),
@@ -412,27 +461,25 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
          sb + 37, "valu (tree rooting) + hbm"),
         ("turn", "export_kernel (n_moves only)", lambda: env.turn(out=tn), sb // 2 + 1, "launch"),
         ("check_win", "check_win_kernel", lambda: env.check_win(out=cw), sb // 2 + 2, "launch"),
-        ("node_info", "node_info_kernel", lambda: env.node_info(out=ni), sb + 18, "valu (CPython tuple hash)"),
-        ("expand", "expand_kernel", lambda: env.expand(act, out=xp), sb + 1 + 2 * sb + 1 + 2 * 18, "valu (two steps + two tuple hashes)"),
+        # winner + terminal + legal + the native position key (state_key): what a device-side search asks for
+        ("node_info", "node_info_kernel<1024, false>", lambda: env.node_info(out=ni), sb + 18, "hbm"),
+        ("state_keys", "node_info_kernel<1024, false> (state_key alone)", lambda: env.state_keys(out=sk), sb + 8, "hbm"),
+        # the same + CPython's hash(tuple(board) + tuple(moves)) bit for bit, for host-side dicts of reference code
+        ("node_info_python_key", "node_info_kernel<1024, true>", lambda: env.node_info(out=ni_py), sb + 26, "valu (CPython tuple hash)"),
+        ("expand", "expand_kernel<1024, false>", lambda: env.expand(act, out=xp), sb + 1 + 2 * sb + 1 + 2 * 18, "hbm + valu (a step with two path reversals)"),
+        ("expand_python_key", "expand_kernel<1024, true>", lambda: env.expand(act, out=xp_py), sb + 1 + 2 * sb + 1 + 2 * 26,
+         "valu (the same + two tuple hashes)"),
         ("rollout", "rollout_kernel", lambda: env.rollout(out=ro), sb + 2, "valu (playouts to the end from boards five plies deep)"),
         ("encode", "encode_kernel", lambda: env.encode(out=enc), sb + 720 + 36, "hbm (write)"),
     ]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = []
     for name, kernel, fn, algo, bound in rows:
-        us = []
-        for _ in range(regions):
-            for _ in range(3):
-                fn()
-            e0.record()
-            for _ in range(K):
-                fn()
-            e1.record()
-            torch.cuda.synchronize(dev)
-            us.append(e0.elapsed_time(e1) * 1e3 / K)
+        us, us_eager = time_calls(torch, dev, fn, K, regions)
         u = median(us)
         out.append({"name": "row_%s_1048576_boards" % name, "boards": n, "mode": "row", "kernel": kernel, "steps": K,
                     "regions": regions, "us_per_launch": u, "best_region_us_per_launch": min(us),
+                    "timing": "hipGraph of %d launches replayed (device-paced); us_per_python_call = the same calls eager" % K,
+                    "us_per_python_call": median(us_eager),
                     "algorithmic_bytes_per_board": algo, "achieved_GBps": algo * n / (u * 1e-6) / 1e9,
                     "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": bound})
     return out
@@ -447,52 +494,46 @@ FUSED_ISSUE_NS_PER_WAVE_PLY = 220.8
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):
-    """BASELINE config 5's unit: one batched MCTS expansion of 65 536 (state, action) pairs + the node
-    bookkeeping of the parents + one fused random playout per board, through VecEnv with reused buffers
-    (mcts.py:233-267, 20-27 / 52-65 / 93-94, 185-198), timed as one unit."""
+    """BASELINE config 5's unit: one MCTS rollout below each of 65 536 selected nodes (mcts.py:166-176: select ->
+    _expand_child -> num_simulations x _simulate FROM THE LEAF -> the value for _backpropogate; :210-221,233-267) =
+    qttt_expand_rollout, ONE launch: the expansion, both children's bookkeeping (winner, terminal, legal mask, native
+    position key) and the playouts from each child, through VecEnv with reused buffers.  Beside it the same unit as
+    three launches (expand, then rollout_many on each child buffer) — what round 3 had, now playing out the children."""
     from qtttgym_amd import VecEnv
     env = VecEnv(n, device=dev, seed=args.seed)
     for _ in range(4):
         env.step_raw(env.sample_actions())
     act = torch.randint(0, 36, (n,), dtype=torch.uint8, device=dev)
-    ex, ni, ro, rm = env.expand(act), env.node_info(), env.rollout(), env.rollout_many(10)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-    def timed(unit):
-        us = []
-        for _ in range(8):
-            for _ in range(5):
-                unit()
-            e0.record()
-            for _ in range(K):
-                unit()
-            e1.record()
-            torch.cuda.synchronize(dev)
-            us.append(e0.elapsed_time(e1) * 1e3 / K)
-        return us
-
-    def unit():
+    x1, x10 = env.expand_rollout(act, 1), env.expand_rollout(act, 10)
+    ex = env.expand(act, python_key=False)
+    r1 = (ex["child0"].rollout_many(1), ex["child1"].rollout_many(1))
+    r10 = (ex["child0"].rollout_many(10), ex["child1"].rollout_many(10))
+    def three(S, r):
         env.expand(act, out=ex)
-        env.node_info(out=ni)
-        env.rollout(out=ro)
-
-    def unit10():                                  # mcts.py:131,170-176: num_simulations = 10 playouts per leaf
-        env.expand(act, out=ex)
-        env.node_info(out=ni)
-        env.rollout_many(10, out=rm)
-    us = timed(unit)
-    us10 = timed(unit10)
+        ex["child0"].rollout_many(S, step_idx0=0, out=r[0])
+        ex["child1"].rollout_many(S, step_idx0=16 * S, out=r[1])
+    us1, us1_eager = time_calls(torch, dev, lambda: env.expand_rollout(act, 1, out=x1), K, 8)
+    us10, us10_eager = time_calls(torch, dev, lambda: env.expand_rollout(act, 10, out=x10), K, 8)
+    us1_3, us1_3_eager = time_calls(torch, dev, lambda: three(1, r1), K, 8)
+    us10_3, us10_3_eager = time_calls(torch, dev, lambda: three(10, r10), K, 8)
     sb = env.state.numel() // ((n + 63) // 64 * 64)
-    # expand: state + action in, two children + n_children + per-child winner/terminal/legal/key out;
-    # node_info: state in, 18 B out; rollout: state in, result + plies out
-    algo = (sb + 1 + 2 * sb + 1 + 2 * (1 + 1 + 8 + 8)) + (sb + 18) + (sb + 2)
-    u = median(us)
-    return {"name": "config5_expand_node_info_rollout_65536_boards", "boards": n, "mode": "mcts-unit",
-            "kernel": "expand_kernel + node_info_kernel + rollout_kernel", "steps": K, "regions": len(us),
-            "us_per_unit": u, "best_region_us_per_unit": min(us), "expansions_per_s": n / (u * 1e-6),
-            "us_per_unit_with_10_playouts_per_leaf": median(us10), "playouts_per_s_10_per_leaf": 10 * n / (median(us10) * 1e-6),
+    # state + action in; two children, n_children, per-child winner / terminal / legal / state_key and value_sum out
+    algo = sb + 1 + 2 * sb + 1 + 2 * (1 + 1 + 8 + 8 + 4)
+    u = median(us1)
+    return {"name": "config5_expand_rollout_65536_pairs", "boards": n, "mode": "mcts-unit",
+            "kernel": "expand_rollout_kernel<256, false>", "steps": K, "regions": len(us1),
+            "us_per_unit": u, "best_region_us_per_unit": min(us1), "expansions_per_s": n / (u * 1e-6),
+            "us_per_unit_with_10_playouts_per_leaf": median(us10),
+            "playouts_per_s_10_per_leaf": 10 * float((x10["n_children"].to(torch.int64)).sum()) / (median(us10) * 1e-6),
+            "children_per_pair": float(x10["n_children"].to(torch.float32).mean()),
+            "us_per_unit_as_three_launches": median(us1_3), "us_per_unit_as_three_launches_10_playouts": median(us10_3),
+            "timing": "hipGraph of %d units replayed (device-paced); *_python_call = the same calls eager" % K,
+            "us_per_unit_python_call": median(us1_eager), "us_per_unit_with_10_playouts_python_call": median(us10_eager),
+            "us_per_unit_as_three_launches_python_calls": median(us1_3_eager),
+            "us_per_unit_as_three_launches_10_playouts_python_calls": median(us10_3_eager),
             "algorithmic_bytes_per_board_unit": algo, "achieved_GBps": algo * n / (u * 1e-6) / 1e9,
-            "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "launch + valu (3 kernels, 65 536 boards each)"}
+            "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bound": "launch + valu (one launch; one lane per (pair, simulation, child))"}
 
 
 # ---------------------------------------------------------------------------- one rank
@@ -567,23 +608,38 @@ def run(args):
 
     gather = None
     if use_dist:
-        # episode counters: the only exchange in the design, once per run, off the timed path
-        cnt = torch.stack([term_count, win_count]).to(coll_dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        term_count, win_count = cnt[0], cnt[1]
-        # and the optional one: a gather of per-board returns (4 B per board) to rank 0, timed on its
-        # own (RCCL over xGMI on a multi-GPU node; never part of a step)
-        from qtttgym_amd.dist import gather_returns
-        ret = env._reward.clone().to(coll_dev)
-        gather_returns(ret, dst=0)                           # untimed: connection set-up of the gather
-        torch.cuda.synchronize(dev)
-        barrier()
-        tg0 = time.perf_counter()
-        gathered = gather_returns(ret, dst=0)
-        torch.cuda.synchronize(dev)
-        tg = all_max(time.perf_counter() - tg0)
-        gather = {"ms": tg * 1e3, "bytes_per_rank": 4 * B, "backend": backend,
-                  "boards_gathered": None if gathered is None else int(gathered.numel())}
+        # Everything below is OPTIONAL bookkeeping off the timed path (the step has no collective): a failure of
+        # any of it — e.g. the very first RCCL gather on a node this code has never seen — is reported inside the
+        # line and never takes the scaling value down with it.
+        # episode counters: once per run
+        try:
+            cnt = torch.stack([term_count, win_count]).to(coll_dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            term_count, win_count = cnt[0], cnt[1]
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write("bench.py: episode-counter all_reduce failed on rank %d: %r\n" % (rank, e))
+        # and a gather of per-board returns (4 B per board) to rank 0, timed on its own (RCCL over xGMI on a
+        # multi-GPU node; never part of a step).  QTTT_BENCH_NO_GATHER=1 skips it.
+        if os.environ.get("QTTT_BENCH_NO_GATHER") == "1":
+            gather = {"skipped": "QTTT_BENCH_NO_GATHER=1"}
+        else:
+            try:
+                from qtttgym_amd.dist import gather_returns
+                if os.environ.get("QTTT_BENCH_FAIL_GATHER") == "1":      # test hook (tests/test_round4_gpu.py)
+                    raise RuntimeError("QTTT_BENCH_FAIL_GATHER=1: injected failure of the returns gather")
+                ret = env._reward.clone().to(coll_dev)
+                gather_returns(ret, dst=0)                           # untimed: connection set-up of the gather
+                torch.cuda.synchronize(dev)
+                barrier()
+                tg0 = time.perf_counter()
+                gathered = gather_returns(ret, dst=0)
+                torch.cuda.synchronize(dev)
+                tg = all_max(time.perf_counter() - tg0)
+                gather = {"ms": tg * 1e3, "bytes_per_rank": 4 * B, "backend": backend,
+                          "boards_gathered": None if gathered is None else int(gathered.numel())}
+            except Exception as e:                               # noqa: BLE001
+                sys.stderr.write("bench.py: returns gather failed on rank %d: %r\n" % (rank, e))
+                gather = {"error": "%s: %s" % (type(e).__name__, e), "backend": backend}
 
     rc = 0
     if rank == 0:
@@ -623,12 +679,26 @@ def run(args):
                              "traffic_source": None if traffic is None else PMC_SUMMARY,
                              "kernel": kernel_label(args.mode, bpl, blk), "launch_us": launch_s * 1e6,
                              "algorithmic_bytes_per_board_step": algo_bytes,
-                             "algorithmic_bytes_per_launch": algo_bytes * B},
+                             "algorithmic_bytes_per_launch": algo_bytes * B,
+                             # the guide's measured float4-copy rate: what a kernel that moves only its algorithmic
+                             # bytes can reach on this part
+                             "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                             # 1 048 576 boards x 16 B of state live in the 256 MB Infinity Cache: `achieved` above is fabric
+                             # traffic, not HBM traffic.  The same kernel with a working set that cannot be cached
+                             # (the 16 M-board leg, filled in below when the legs run):
+                             "state_resident_in_infinity_cache": bool(B * algo_bytes <= 256 << 20),
+                             "beyond_cache": None},
             }
             actions = wl.actions
             del wl
             if world == 1 and not args.no_legs:
                 out["legs"] = run_legs(torch, dev, args)
+                big = [l for l in out["legs"] if l["name"].startswith("beyond_infinity_cache")]
+                if big:
+                    out["roofline"]["beyond_cache"] = {
+                        "boards": big[0]["boards"], "launch_us": big[0]["us_per_step"], "achieved": big[0]["achieved_GBps"],
+                        "frac": big[0]["frac"], "frac_of_achievable": big[0]["achieved_GBps"] / HBM_ACHIEVABLE_GBS,
+                        "kernel": big[0]["kernel"], "working_set_MB": big[0]["boards"] * state_bytes / 1e6}
             if not args.no_cpu_baseline and world == 1:                 # rank 0 at N = 1 only
                 # bounded sample: the first <=256 recorded steps of every board of rank 0, ~15 s of CPU
                 t_cpu = min(K + W, 256)

@@ -204,6 +204,15 @@ __device__ __forceinline__ void lite_update_winner(const Lite &s, const uint8_t 
     terminal = (s.n == 9u || hx || ho) ? 1 : 0;
 }
 
+// The same from what the step already knows: xo = who holds a line (step_line_xo), the state's done bit = a line or
+// nine moves.  Only when both players hold a line do the rounds matter (mcts.py:54-56): that rare case takes the
+// round-aware path above.
+__device__ __forceinline__ void update_winner_from_step(u64 P, u32 xo, const uint8_t *lut, int &winner, int &terminal) {
+    winner = (xo & 1u) ? 1 : ((xo & 2u) ? 0 : -1);
+    terminal = (int)((u32)(P >> 63));
+    if (xo == 3u) lite_update_winner(lite_unpack(P), lut, winner, terminal);
+}
+
 // GameState.actions (mcts.py:20-27) in ind2move order (mcts.py:339-343): the pairs (i, j > i) of
 // row i are the empty squares above i, eight rows at offsets 0, 8, 15, 21, 26, 30, 33, 35
 __device__ __forceinline__ u64 fast_legal_mask(u32 cl) {
@@ -240,6 +249,29 @@ template <int BLOCK>
 __device__ inline void fill_legal_lut(u64 *dst) {
     for (u32 w = threadIdx.x; w < 512u; w += BLOCK) dst[w] = g_legal_lut.m[w];
 }
+// The same in two halves, for kernels that stream their state: the table words are REQUESTED before the state loads
+// and stored to LDS behind them.  Vector loads return in order, so the wait in front of the LDS store then covers
+// the table words only and the workgroup barrier is passed while the state is still in flight (a table loaded
+// after the state ties the barrier — and every wave of the workgroup — to the slowest wave's state data).
+template <int BLOCK>
+struct LegalLutWords {
+    static constexpr int N = (512 + BLOCK - 1) / BLOCK;
+    u64 w[N];
+    __device__ __forceinline__ void request() {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const u32 i = threadIdx.x + (u32)k * BLOCK;
+            w[k] = i < 512u ? g_legal_lut.m[i] : 0ull;
+        }
+    }
+    __device__ __forceinline__ void store(u64 *dst) const {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const u32 i = threadIdx.x + (u32)k * BLOCK;
+            if (i < 512u) dst[i] = w[k];
+        }
+    }
+};
 
 // GameState.__hash__ (mcts.py:93-94) = hash(tuple(board) + tuple(moves)) under CPython >= 3.8
 // (Objects/tupleobject.c tuplehash, xxHash-style; hash(int) = the int, hash(-1) = -2).  One

@@ -512,12 +512,11 @@ int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *
     if (expand_rows_misaligned(winner, terminal, legal, key, state_key)) return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
     const ExpandOut o = {n_children, winner, terminal, (u64 *)legal, key, (u64 *)state_key};
-    // workgroup size by batch, as node_info (tools/rowbench, 256 / 512 / 1024 threads: 1 M pairs 27.4 / 26.6 / 25.9 us,
-    // 64 K pairs 5.6 / 6.0 / 7.9)
-#define QTTT_EX(BLK, PK) hipLaunchKernelGGL((expand_kernel<BLK, PK>), dim3(blocks_for(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, \
-                                            p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, n)
-    if (n >= 384 * 1024) { if (key) QTTT_EX(1024, true); else QTTT_EX(1024, false); }
-    else                 { if (key) QTTT_EX(256, true);  else QTTT_EX(256, false); }
+    // 256-thread workgroups at every batch size (tools/rowbench, 1 M pairs with native keys: 19.1 us against 20.3 with
+    // 1024 threads; 64 K pairs: 4.4 against 4.9); with the CPython keys the two are level (29.4)
+#define QTTT_EX(PK) hipLaunchKernelGGL((expand_kernel<256, PK>), dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, \
+                                       p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, n)
+    if (key) QTTT_EX(true); else QTTT_EX(false);
 #undef QTTT_EX
     return launch_status();
 }
@@ -537,6 +536,24 @@ int qttt_expand_rollout(const void *state, const uint8_t *action36, void *child0
     if (child0) c0 = planes(child0, n);
     if (child1) c1 = planes(child1, n);
     const ExpandOut o = {n_children, winner, terminal, (u64 *)legal, key, (u64 *)state_key};
+    // Two mappings with the same results (tools/rowbench): a lane per (pair, simulation, child) for the latency-bound
+    // case — few playouts in all — and the job-list kernel, whose workgroups expand P pairs once and deal the playouts of
+    // the children that exist to their lanes, wherever the playouts are the work.  P: as many pairs as lanes, but at
+    // least ~1 000 workgroups so that a small batch still covers the chip.
+    const int64_t playouts = n * (int64_t)n_sims;
+    if (playouts >= 262144) {
+        int64_t P = n / 1024;
+        if (P > XR_MAX_PAIRS) P = XR_MAX_PAIRS;
+        if (P < 8) P = 8;
+        const u32 ppb = (u32)P;
+        const unsigned grid = (unsigned)((n + ppb - 1) / ppb);
+#define QTTT_XJ(PK) hipLaunchKernelGGL((expand_rollout_jobs_kernel<BLK, PK>), dim3(grid), dim3(BLK), 0, (hipStream_t)stream,  \
+                                       p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, (u64)seed, step_idx0,                 \
+                                       (u64)board_offset, (u32)n_sims, ppb, value_sum, result, n)
+        if (key) QTTT_XJ(true); else QTTT_XJ(false);
+#undef QTTT_XJ
+        return launch_status();
+    }
     const u32 ppb = (u32)(BLK / (2 * n_sims));                    // whole pairs per workgroup
     const unsigned grid = (unsigned)((n + ppb - 1) / ppb);
 #define QTTT_XR(PK) hipLaunchKernelGGL((expand_rollout_kernel<BLK, PK>), dim3(grid), dim3(BLK), 0, (hipStream_t)stream,     \

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(BLOCK) void node_info_kernel(
     V64 p, q;
     p.v[0] = p.v[1] = q.v[0] = q.v[1] = 0ull;
     const bool want_q = PYKEY || skey != nullptr;                       // plane Q: only the keys read it (the x nibbles)
-    if (i0 + 1 < n) {                                                   // requested before the table fills
+    LegalLutWords<BLOCK> lw;
+    if (legal) lw.request();                                            // in front of the state loads, stored behind them
+    if (i0 + 1 < n) {
         p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]);
         if (want_q) q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);
     } else if (i0 < n) {
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(BLOCK) void node_info_kernel(
         if (want_q) q.v[0] = pQ[i0];
     }
     if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
-    if (legal) fill_legal_lut<BLOCK>(ltbl);
-    if (winner || terminal || legal || PYKEY) fill_line_lut<BLOCK>(lut);   // ends with the workgroup barrier
+    if (legal) lw.store(ltbl);
+    if (winner || terminal || legal || PYKEY) fill_line_lut<BLOCK>(lut);   // computed; ends with the workgroup barrier
     if (i0 >= n) return;
     const bool two = i0 + 1 < n;
     typedef Vec<u64, 2> V64x;
@@ -117,8 +119,8 @@ struct ExpandOut {
 // the bookkeeping of the two children of one pair, from their packed words (shared by expand_kernel and
 // expand_rollout_kernel's writer lanes)
 template <bool PYKEY>
-__device__ __forceinline__ void expand_bookkeeping(u32 kids, const u64 kidP[2], const u64 kidQ[2], const ExpandOut &o, int64_t i,
-                                                   const uint8_t *lut, const u64 *htbl, const u64 *ltbl) {
+__device__ __forceinline__ void expand_bookkeeping(u32 kids, const u64 kidP[2], const u64 kidQ[2], u32 xo0, u32 xo1,
+                                                   const ExpandOut &o, int64_t i, const uint8_t *lut, const u64 *htbl, const u64 *ltbl) {
     typedef Vec<u64, 2> V64;
     const bool h0 = kids >= 1u, h1 = kids >= 2u;
     if (o.n_children) o.n_children[i] = (uint8_t)kids;
@@ -128,23 +130,24 @@ __device__ __forceinline__ void expand_bookkeeping(u32 kids, const u64 kidP[2], 
         k2.v[1] = h1 ? state_key(kidP[1], (u32)kidQ[1]) : 0ull;
         store_stream(&reinterpret_cast<V64 *>(o.skey)[i], k2);
     }
-    if (!(o.winner || o.terminal || o.legal || PYKEY)) return;
-    const Lite s0 = lite_unpack(kidP[0]), s1 = lite_unpack(kidP[1]);
-    if (o.winner || o.terminal) {
+    if (o.winner || o.terminal) {                    // from the line test the step just made (update_winner, mcts.py:52-65)
         int w0, t0, w1, t1;
-        lite_update_winner(s0, lut, w0, t0);
-        lite_update_winner(s1, lut, w1, t1);
+        update_winner_from_step(kidP[0], xo0, lut, w0, t0);
+        update_winner_from_step(kidP[1], xo1, lut, w1, t1);
         const u32 wv = (u32)((h0 ? w0 : -1) & 0xFF) | ((u32)((h1 ? w1 : -1) & 0xFF) << 8);
         const u32 tv = (h0 ? (u32)t0 : 0u) | ((h1 ? (u32)t1 : 0u) << 8);
         if (o.winner) reinterpret_cast<uint16_t *>(o.winner)[i] = (uint16_t)wv;      // [n,2] rows: 2-byte / 16-byte aligned by the host check
         if (o.terminal) reinterpret_cast<uint16_t *>(o.terminal)[i] = (uint16_t)tv;
     }
-    if (o.legal) {
-        V64 l2;
-        l2.v[0] = h0 ? ltbl[s0.cl] : 0ull; l2.v[1] = h1 ? ltbl[s1.cl] : 0ull;
+    if (o.legal) {                                   // GameState.actions (mcts.py:20-27): a function of the classical squares,
+        V64 l2;                                      // the implicit autofill (eight classical squares) counted as the ninth
+        const u32 c0 = (u32)(kidP[0] >> (32u + P1_CL_SHIFT)) & 0x1FFu, c1 = (u32)(kidP[1] >> (32u + P1_CL_SHIFT)) & 0x1FFu;
+        l2.v[0] = h0 ? ltbl[__builtin_popcount(c0) == 8 ? 0x1FFu : c0] : 0ull;
+        l2.v[1] = h1 ? ltbl[__builtin_popcount(c1) == 8 ? 0x1FFu : c1] : 0ull;
         store_stream(&reinterpret_cast<V64 *>(o.legal)[i], l2);
     }
     if (PYKEY) {
+        const Lite s0 = lite_unpack(kidP[0]), s1 = lite_unpack(kidP[1]);
         int64_t k0, k1;
         fast_py_hash_pair(s0, (u32)(kidP[0] >> 32), (u32)kidQ[0], s1, (u32)(kidP[1] >> 32), (u32)kidQ[1], htbl, k0, k1);
         V64 k2;
@@ -153,6 +156,9 @@ __device__ __forceinline__ void expand_bookkeeping(u32 kids, const u64 kidP[2], 
     }
 }
 
+// One (state, action) pair per lane.  Measured and not adopted (tools/rowbench, 1 M pairs, us per launch): two pairs per
+// lane with 16-byte plane accesses — 31 - 33 against 19 (the two children of two pairs do not fit the registers of a
+// full-occupancy wave); 1024-thread workgroups 20.3 against 19.1 with 256.
 template <int BLOCK, bool PYKEY>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(
     const u64 *pP, const u64 *pQ, const uint8_t *action36,
@@ -161,25 +167,27 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(
     __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
     __shared__ u64 ltbl[512];
     int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;  // requested before the table fills
+    LegalLutWords<BLOCK> lw;
+    if (out.legal) lw.request();                     // in front of the state loads, stored behind them
+    const u64 P = i < n ? load_stream(&pP[i]) : 0ull, Q = i < n ? load_stream(&pQ[i]) : 0ull;
     const u32 a = i < n ? (u32)action36[i] : 0u;
     if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
-    if (out.legal) fill_legal_lut<BLOCK>(ltbl);
-    fill_line_lut<BLOCK>(lut);                       // ends with the workgroup barrier
+    if (out.legal) lw.store(ltbl);
+    fill_line_lut<BLOCK>(lut);                       // computed; ends with the workgroup barrier
     if (i >= n) return;
     const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;            // (0,0) = a noop for bad indices
     const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
     // both children in one pass: validity, components, append, qstructs and classical update are shared, only the
     // path reversal and the line test run per child (step_core_both)
-    u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b;
-    const u32 kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b);   // mcts.py:245
+    u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b, xo0, xo1;
+    const u32 kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b, xo0, xo1);   // mcts.py:245
     u64 kidP[2], kidQ[2];
     kidP[0] = (u64)P0a | ((u64)P1a << 32);
     kidP[1] = (u64)P0b | ((u64)P1b << 32);
     kidQ[0] = kidQ[1] = (u64)Q0 | ((u64)Q1 << 32);
     store_stream(&c0P[i], kidP[0]); store_stream(&c0Q[i], kidQ[0]);
     store_stream(&c1P[i], kidP[1]); store_stream(&c1Q[i], kidQ[1]);
-    expand_bookkeeping<PYKEY>(kids, kidP, kidQ, out, i, lut, htbl, ltbl);
+    expand_bookkeeping<PYKEY>(kids, kidP, kidQ, xo0, xo1, out, i, lut, htbl, ltbl);
 }
 
 // MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
@@ -295,8 +303,8 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
     if (valid) {
         const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;
         const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
-        u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b;
-        kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b);
+        u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b, xo0, xo1;
+        kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b, xo0, xo1);
         if (rem == 0u) {                                        // this pair's writer
             u64 kidP[2], kidQ[2];
             kidP[0] = (u64)P0a | ((u64)P1a << 32);
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
             kidQ[0] = kidQ[1] = (u64)Q0 | ((u64)Q1 << 32);
             if (c0P) { c0P[i] = kidP[0]; c0Q[i] = kidQ[0]; }
             if (c1P) { c1P[i] = kidP[1]; c1Q[i] = kidQ[1]; }
-            expand_bookkeeping<PYKEY>(kids, kidP, kidQ, out, i, lut, htbl, ltbl);
+            expand_bookkeeping<PYKEY>(kids, kidP, kidQ, xo0, xo1, out, i, lut, htbl, ltbl);
         }
         if (child < kids) {
             u32 P0 = child ? P0b : P0a, P1 = child ? P1b : P1a;
@@ -323,6 +331,110 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
     if (threadIdx.x < 2u * pairs_per_block) {
         const int64_t o = (int64_t)blockIdx.x * pairs_per_block * 2 + threadIdx.x;
         if (o < 2 * n) value_sum[o] = acc[threadIdx.x];
+    }
+}
+
+// The same operator for batches where the playouts are the work (many simulations per child, or many pairs): a lane per
+// (pair, simulation, child) leaves the lanes of children that do not exist idle (a collapse happens on ~22 % of the
+// moves: 39 % of the child slots are empty) and redoes the expansion in every lane.  Here a workgroup owns P pairs:
+//   1. lane t < P expands pair t once, writes the children and their bookkeeping, and leaves the two child states in LDS;
+//   2. a workgroup scan over the pairs' child counts numbers the children that exist ("units");
+//   3. the playouts of all units — unit u, simulation s is job u * n_sims + s — are dealt to the lanes in job order, so
+//      every wave but the last of a workgroup runs full, and neighbouring lanes play the same child (similar lengths);
+//   4. per-child sums through LDS adds, as above.
+// Same results as expand_rollout_kernel, bit for bit.
+constexpr int XR_MAX_PAIRS = 256;
+template <int BLOCK, bool PYKEY>
+__global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
+    const u64 *pP, const u64 *pQ, const uint8_t *action36,
+    u64 *c0P, u64 *c0Q, u64 *c1P, u64 *c1Q, ExpandOut out,
+    u64 seed, u32 step_idx0, u64 board_offset, u32 n_sims, u32 pairs_per_block,
+    int32_t *value_sum, int8_t *result, int64_t n) {
+    static_assert(BLOCK >= XR_MAX_PAIRS, "one pair per lane in the expansion phase");
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
+    __shared__ uint8_t nth9[512 * 9];
+    __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
+    __shared__ u64 ltbl[512];
+    __shared__ u64 kidPs[XR_MAX_PAIRS * 2];                     // [pair][child] plane-P word; plane Q is the same for both
+    __shared__ u64 kidQs[XR_MAX_PAIRS];
+    __shared__ int acc[XR_MAX_PAIRS * 2];
+    __shared__ uint16_t unit_tbl[XR_MAX_PAIRS * 2];             // unit -> pair << 1 | child
+    __shared__ u32 wave_tot[BLOCK / 64];
+    const u32 t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * pairs_per_block;
+    const int64_t i = base + t;
+    const bool valid = t < pairs_per_block && i < n;
+    LegalLutWords<BLOCK> lw;
+    if (out.legal) lw.request();                                // in front of the state loads, stored behind them
+    const int64_t il = valid ? i : 0;
+    const u64 P = pP[il], Q = pQ[il];
+    const u32 a = (u32)action36[il];
+    if (t < XR_MAX_PAIRS * 2) acc[t] = 0;
+    fill_policy_lut<BLOCK>(plut);
+    fill_nth9<BLOCK>(nth9);
+    if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
+    if (out.legal) lw.store(ltbl);
+    fill_line_lut<BLOCK>(lut);                                  // ends with the workgroup barrier
+    // ---- 1. the expansions
+    u32 kids = 0;
+    if (valid) {
+        const u32 pr = a < 36u ? (u32)g_pair_lut.b[a] : 0u;
+        const u32 act = (pr & 0xFu) | ((pr >> 4) << 8);
+        u32 Q0 = (u32)Q, Q1 = (u32)(Q >> 32), P0a, P1a, P0b, P1b, xo0, xo1;
+        kids = step_core_both((u32)P, (u32)(P >> 32), Q0, Q1, act, lut, P0a, P1a, P0b, P1b, xo0, xo1);
+        u64 kidP[2], kidQ[2];
+        kidP[0] = (u64)P0a | ((u64)P1a << 32);
+        kidP[1] = (u64)P0b | ((u64)P1b << 32);
+        kidQ[0] = kidQ[1] = (u64)Q0 | ((u64)Q1 << 32);
+        kidPs[2u * t] = kidP[0]; kidPs[2u * t + 1u] = kidP[1]; kidQs[t] = kidQ[0];
+        if (c0P) { store_stream(&c0P[i], kidP[0]); store_stream(&c0Q[i], kidQ[0]); }
+        if (c1P) { store_stream(&c1P[i], kidP[1]); store_stream(&c1Q[i], kidQ[1]); }
+        expand_bookkeeping<PYKEY>(kids, kidP, kidQ, xo0, xo1, out, i, lut, htbl, ltbl);
+        if (result)                                             // children that do not exist: every simulation reads 0
+            for (u32 c = kids; c < 2u; ++c)
+                for (u32 s = 0; s < n_sims; ++s) result[(i * 2 + c) * (int64_t)n_sims + s] = 0;
+    }
+    // ---- 2. number the children that exist: exclusive scan of `kids` over the workgroup (wave scan + wave totals)
+    u32 incl = kids;
+#pragma unroll
+    for (u32 d = 1; d < 64u; d <<= 1) {
+        const u32 up = (u32)__shfl_up((int)incl, d, 64);
+        if ((t & 63u) >= d) incl += up;
+    }
+    if ((t & 63u) == 63u) wave_tot[t >> 6] = incl;
+    __syncthreads();
+    u32 before = 0, units = 0;
+#pragma unroll
+    for (u32 w = 0; w < (u32)(BLOCK / 64); ++w) {
+        const u32 x = wave_tot[w];
+        before += w < (t >> 6) ? x : 0u;
+        units += x;
+    }
+    const u32 first = before + incl - kids;
+    for (u32 c = 0; c < kids; ++c) unit_tbl[first + c] = (uint16_t)((t << 1) | c);
+    __syncthreads();
+    // ---- 3. the playouts, dealt in job order
+    const u32 jobs = units * n_sims;
+    for (u32 j = t; j < jobs; j += BLOCK) {
+        const u32 u = j / n_sims, sim = j - u * n_sims;
+        const u32 e = unit_tbl[u], pl = e >> 1, child = e & 1u;
+        const u64 cP = kidPs[e], cQ = kidQs[pl];
+        u32 P0 = (u32)cP, P1 = (u32)(cP >> 32), Q0 = (u32)cQ, Q1 = (u32)(cQ >> 32);
+        const u32 child_real = (P1 >> P1_N_SHIFT) & 0xFu;
+        const int64_t ip = base + pl;
+        playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)ip), seed, step_idx0 + (child * n_sims + sim) * QTTT_SIM_STRIDE,
+                lut, plut, nth9);
+        int w, tm;
+        lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, tm);
+        const int r = w < 0 ? 0 : (w ? 1 : -1);                 // MCTS._reward, mcts.py:200-209
+        if (r) atomicAdd(&acc[e], (child_real & 1u) ? -r : r);  // leaf.turn (mcts.py:174)
+        if (result) result[(ip * 2 + child) * (int64_t)n_sims + sim] = (int8_t)r;
+    }
+    __syncthreads();
+    if (t < 2u * pairs_per_block) {
+        const int64_t o = base * 2 + t;
+        if (o < 2 * n) value_sum[o] = acc[t];
     }
 }
 

@@ -232,28 +232,43 @@ __device__ inline void fill_nth9(uint8_t *nth9) {
         }
     }
 }
-// the same table as a constant, for kernels that LOAD it (the one-launch-per-step policy kernel requests its words
-// in front of the state loads and stores them to LDS behind them, like the policy table: no compute in front of the
-// workgroup barrier)
-struct Nth9Lut {
-    u32 w[512 * 9 / 4];
-    constexpr Nth9Lut() : w() {
+// The one-launch-per-step policy kernel keeps the same information as ONE word per mask: nibble r of row32[m] = the
+// r-th empty square of m, r = 0..7 (rank 8 exists only for the empty board, where the square is 8), and the pair table
+// pre-scaled to bit offsets: pair16[e][k] = 4 * rank_lo | (4 * rank_hi) << 5.  The row (indexed by the mask) and the
+// pair (indexed by the hash) are then two INDEPENDENT LDS reads followed by two bit-field extracts, instead of the pair
+// read followed by two dependent byte reads; and the tables are 2 KB + 720 B, loaded (requested in front of the state
+// loads, stored to LDS behind them) rather than computed.
+struct PolicyRows {
+    u32 row32[512];
+    uint16_t pair16[10 * 36];
+    constexpr PolicyRows() : row32(), pair16() {
         for (u32 m = 0; m < 512u; ++m) {
-            uint8_t row[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            u32 r = 0;
-            for (u32 v = 0; v < 9; ++v) {                  // the same fill as fill_nth9: entries past the population
-                row[r] = (uint8_t)v;                       // hold whatever the last rejected square left there
-                r += m >> v & 1u;
-            }
-            for (u32 k = 0; k < 9; ++k) {
-                const u32 byte = m * 9u + k;
-                w[byte >> 2] |= (u32)row[k] << (8u * (byte & 3u));
-            }
+            u32 r = 0, w = 0;
+            for (u32 v = 0; v < 9; ++v)
+                if (m >> v & 1u) { if (r < 8u) w |= v << (4u * r); ++r; }
+            row32[m] = w;
+        }
+        for (int e = 0; e < 10; ++e) {
+            int k = 0;
+            for (int i = 0; i < e; ++i)
+                for (int j = i + 1; j < e; ++j) pair16[e * 36 + k++] = (uint16_t)((4 * i) | ((4 * j) << 5));
+            for (; k < 36; ++k) pair16[e * 36 + k] = 0;
         }
     }
 };
-__device__ const Nth9Lut g_nth9_lut = Nth9Lut();
-constexpr u32 NTH9_WORDS = 512 * 9 / 4;
+__device__ const PolicyRows g_policy_rows = PolicyRows();
+constexpr u32 POLICY_ROWS_WORDS = (512 * 4 + 10 * 36 * 2) / 4;      // 692
+// the policy's action for the empty-square mask `empty` (>= 2 squares) from hash word h2: lo | hi << 8
+__device__ __forceinline__ u32 policy_action_rows(const u32 *rows, u32 empty, u32 h2) {
+    const uint16_t *pair16 = reinterpret_cast<const uint16_t *>(rows + 512);
+    const u32 e = (u32)__builtin_popcount(empty);
+    const u32 row = rows[empty];
+    const u32 ent = pair16[e * 36u + __umulhi(h2, (e * (e - 1u)) >> 1)];
+    const u32 lo = __builtin_amdgcn_ubfe(row, ent & 31u, 4u);
+    const u32 hs = ent >> 5;
+    const u32 hi = hs == 32u ? 8u : __builtin_amdgcn_ubfe(row, hs, 4u);
+    return lo | (hi << 8);
+}
 
 // the policy's action for the empty-square mask `empty` (>= 2 squares) from hash word h2: lo | hi << 8
 __device__ __forceinline__ u32 policy_action_nth9(const uint8_t *plut, const uint8_t *nth9, u32 empty, u32 h2) {

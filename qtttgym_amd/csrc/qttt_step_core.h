@@ -122,6 +122,21 @@ __device__ __forceinline__ u32 step_line(u32 P0, u32 &P1, const uint8_t *lut) {
     return win;
 }
 
+// The same for callers that also want to know WHO holds a line (GameState.update_winner, mcts.py:52-65): returns
+// bit 0 = X (player 1) has a line, bit 1 = O (player 2) has one; P1's done bit is updated as by step_line.
+__device__ __forceinline__ u32 step_line_xo(u32 P0, u32 &P1, const uint8_t *lut) {
+    const u32 par4 = P0 & 0x44444444u;
+    const u32 even4 = __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
+                      (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4) | ((P1 << 8) & 0x400u);
+    const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;
+    const u32 pc = (u32)__builtin_popcount(cl4);
+    const u32 O4 = cl4 & ~even4;
+    const u32 X4 = pc >= 8u ? (O4 ^ 0x7FCu) : (cl4 & even4);
+    const u32 wx = (u32)lut[X4], wo = (u32)lut[O4];
+    P1 = (P1 & ~P1_DONE) | ((((wx | wo) | (pc & 8u)) << 28) & P1_DONE);
+    return (wx & 1u) | ((wo & 1u) << 1);
+}
+
 // `lut` is the workgroup's LDS line table (fill_line_lut: one entry per dword, 0x7F = the mask holds a line).
 // Returns 0x7F iff a completed line exists afterwards (else 0); P1's done bit is updated.
 // TRUSTED: the caller guarantees a legal action with action[0] < action[1] (the in-kernel policy of the
@@ -149,8 +164,9 @@ __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32
 // Both values of the collapse bit at once (MCTS._step, mcts.py:233-267): child a = the closing move on lo (bit 0),
 // child b = on hi (bit 1).  Everything but the path reversal and the line test is shared; without a cycle the
 // children are the same board.  Returns n_children: 0 = make_move raises, 1 = no collapse, 2 = collapse.
+// xo_a / xo_b: who holds a line in each child (step_line_xo).
 __device__ __forceinline__ u32 step_core_both(u32 P0, u32 P1, u32 &Q0, u32 &Q1, u32 act, const uint8_t *lut,
-                                              u32 &P0a, u32 &P1a, u32 &P0b, u32 &P1b) {
+                                              u32 &P0a, u32 &P1a, u32 &P0b, u32 &P1b, u32 &xo_a, u32 &xo_b) {
     const StepPrep s = step_prep<false>(P1, Q1, act);
     P0a = P0b = P0;
     P1a = P1b = P1;
@@ -166,8 +182,8 @@ __device__ __forceinline__ u32 step_core_both(u32 P0, u32 P1, u32 &Q0, u32 &Q1, 
         P0b = (u32)Pb;
         P1b = F | ((u32)(Pb >> 32) & 0x3Fu);
     }
-    step_line(P0a, P1a, lut);
-    step_line(P0b, P1b, lut);
+    xo_a = step_line_xo(P0a, P1a, lut);
+    xo_b = step_line_xo(P0b, P1b, lut);
     return s.legal ? (s.cyc ? 2u : 1u) : 0u;
 }
 

@@ -39,12 +39,9 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     u32 last_groups, StepKeySource<DEVSTEP> sk) {
     constexpr u32 TILE_BOARDS = BLOCK * BPL;
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    __shared__ __attribute__((aligned(16))) uint8_t plut[SAMPLE ? POLICY_LUT_WORDS * 4 : 4];
-    // the full "r-th empty square" table of the fused stepper (4.5 KB) where a workgroup has enough boards to pay for
-    // its load: everything but one board per lane in 256-thread workgroups (the launch-bound shapes)
-    constexpr bool NTH9 = SAMPLE && BLOCK * BPL >= 512;
-    constexpr int N9W = NTH9 ? (int)((NTH9_WORDS + BLOCK - 1) / BLOCK) : 1;
-    __shared__ __attribute__((aligned(16))) u32 nth9w[NTH9 ? NTH9_WORDS : 1];
+    // the policy's tables (qttt_state.h PolicyRows: one word per empty-square mask + the pre-scaled pair table)
+    constexpr int PRW = SAMPLE ? (int)((POLICY_ROWS_WORDS + BLOCK - 1) / BLOCK) : 1;
+    __shared__ __attribute__((aligned(16))) u32 prows[SAMPLE ? POLICY_ROWS_WORDS : 1];
     __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
     __shared__ __attribute__((aligned(16))) u32 olut[OBS ? OBS_LUT_BYTES / 4 : 4];
 #ifdef QTTT_DEBUG_STAMPS
@@ -69,16 +66,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     // the streaming loads have been issued: vector loads return in order, so the wait in front of
     // the table's LDS store then covers the table word only, not this wave's state.  The line table
     // is computed.  Either way the workgroup barrier is passed while the state is still in flight.
-    static_assert(!SAMPLE || BLOCK >= (int)POLICY_LUT_WORDS, "one policy-table word per thread");
-    u32 plw = 0, olw = 0;
-    if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) plw = reinterpret_cast<const u32 *>(&g_policy_lut)[threadIdx.x];
+    u32 olw = 0;
     if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olw = (&g_obs_lut.sel[0][0])[threadIdx.x];
-    u32 n9[N9W];
-    if (NTH9) {
+    u32 prw[PRW];
+    if (SAMPLE) {
 #pragma unroll
-        for (int k = 0; k < N9W; ++k) {
+        for (int k = 0; k < PRW; ++k) {
             const u32 w = threadIdx.x + (u32)k * BLOCK;
-            n9[k] = w < NTH9_WORDS ? g_nth9_lut.w[w] : 0u;
+            prw[k] = w < POLICY_ROWS_WORDS ? reinterpret_cast<const u32 *>(&g_policy_rows)[w] : 0u;
         }
     }
     V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
@@ -88,13 +83,12 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     if (!SAMPLE) act = load_stream(&reinterpret_cast<const V16 *>(actions + ib)[g]);
     if (HAS_BITS) bt = load_stream(&reinterpret_cast<const V8 *>(bits + ib)[g]);
     fill_line_lut_nosync<BLOCK>(lut);
-    if (SAMPLE && threadIdx.x < POLICY_LUT_WORDS) reinterpret_cast<u32 *>(plut)[threadIdx.x] = plw;
     if (OBS && threadIdx.x < OBS_LUT_BYTES / 4) olut[threadIdx.x] = olw;
-    if (NTH9) {
+    if (SAMPLE) {
 #pragma unroll
-        for (int k = 0; k < N9W; ++k) {
+        for (int k = 0; k < PRW; ++k) {
             const u32 w = threadIdx.x + (u32)k * BLOCK;
-            if (w < NTH9_WORDS) nth9w[w] = n9[k];
+            if (w < POLICY_ROWS_WORDS) prows[w] = prw[k];
         }
     }
     ObsTiles T;
@@ -116,22 +110,24 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
             if (SAMPLE) {
                 const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
                 const u32 h2 = lowbias32(h1 ^ key_hi);
-                const uint8_t *nth9 = reinterpret_cast<const uint8_t *>(nth9w);
                 bit = h1 >> 31;
                 if (AUTO_RESET) {
                     // a finished board restarts first (empty = all zero); a board that is not done has >= 2 empty
                     // squares (8 classical squares set the done bit), so the policy always finds a legal pair,
                     // lo < hi by construction: the step runs TRUSTED (no validation, no sorting), as in
-                    // step_random_fused_kernel
+                    // step_random_fused_kernel.  A/B, interleaved (tools/stepbench STEPBENCH_RANDOM=1, 1 M boards, us per
+                    // launch): round 3's two-level lookup + validated step 8.08; trusted step alone 7.84; the 4.5 KB
+                    // byte table of the fused stepper 7.67 (but 15.6 against 14.9 in 256-thread workgroups: 4.5 table
+                    // words per thread)
                     const u32 keep = ~(u32)((int)P1 >> 31);
                     P0 &= keep; P1 &= keep; Q0 &= keep; Q1 &= keep;
                     const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
-                    av = NTH9 ? policy_action_nth9(plut, nth9, empty, h2) : policy_action(plut, empty, h2);
+                    av = policy_action_rows(prows, empty, h2);
                     win = step_core<false, true>(P0, P1, Q0, Q1, av, bit, lut);
                 } else {
                     // post-terminal legal moves are accepted; no legal pair -> (0,0), a noop
                     const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
-                    av = (empty & (empty - 1u)) ? (NTH9 ? policy_action_nth9(plut, nth9, empty, h2) : policy_action(plut, empty, h2)) : 0u;
+                    av = (empty & (empty - 1u)) ? policy_action_rows(prows, empty, h2) : 0u;
                     win = step_core<false>(P0, P1, Q0, Q1, av, bit, lut);
                 }
                 act.v[k] = (uint16_t)av;

@@ -98,9 +98,10 @@ def test_bench_default_line_carries_the_legs():
     sb = d["config"]["state_bytes_per_board"]
     for name in ("config2_4096_boards", "config3_262144_boards", "beyond_infinity_cache_16777216_boards",
                  "gym_1048576_boards", "random_1048576_boards", "random_fused_1048576_boards",
-                 "random_fused_262144_boards", "random_fused_4096_boards", "config5_expand_node_info_rollout_65536_boards"):
+                 "random_fused_262144_boards", "random_fused_4096_boards", "config5_expand_rollout_65536_pairs"):
         assert name in legs, name
-    for name in ("observe", "export", "import", "turn", "check_win", "node_info", "expand", "rollout", "encode"):
+    for name in ("observe", "export", "import", "turn", "check_win", "node_info", "state_keys", "node_info_python_key",
+                 "expand", "expand_python_key", "rollout", "encode"):
         assert "row_%s_1048576_boards" % name in legs, name
     assert legs["row_export_1048576_boards"]["algorithmic_bytes_per_board"] == sb + 37
     for l in d["legs"]:
@@ -112,11 +113,37 @@ def test_bench_default_line_carries_the_legs():
     assert legs["beyond_infinity_cache_16777216_boards"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7
     assert 16777216 * (2 * sb) > 256 << 20                                     # the state alone exceeds the Infinity Cache
     assert legs["gym_1048576_boards"]["algorithmic_bytes_per_board_step"] == 2 * sb + 7 + 30
-    c5 = legs["config5_expand_node_info_rollout_65536_boards"]
+    c5 = legs["config5_expand_rollout_65536_pairs"]
     assert c5["us_per_unit_with_10_playouts_per_leaf"] < c5["us_per_unit"] + 9 * 9.0      # ten playouts per leaf: one launch, not ten
+    assert c5["us_per_unit"] < c5["us_per_unit_as_three_launches"]                        # one launch beats the composition
+    assert 1.0 < c5["children_per_pair"] < 1.6
+    # the native position key costs a fraction of the CPython-exact one
+    assert legs["row_node_info_1048576_boards"]["us_per_launch"] < 0.8 * legs["row_node_info_python_key_1048576_boards"]["us_per_launch"]
+    assert legs["row_expand_1048576_boards"]["us_per_launch"] < 0.8 * legs["row_expand_python_key_1048576_boards"]["us_per_launch"]
+    # both roofline fractions in the line: against the spec and against the achievable copy rate, and the same
+    # kernel beyond the Infinity Cache
+    r = d["roofline"]
+    assert r["achievable_peak"] == 6290.0 and abs(r["frac_of_achievable"] - r["achieved"] / 6290.0) < 1e-9
+    assert r["state_resident_in_infinity_cache"] is True
+    bc = r["beyond_cache"]
+    assert bc["boards"] == 16777216 and abs(bc["frac"] - legs["beyond_infinity_cache_16777216_boards"]["frac"]) < 1e-12
+    assert bc["working_set_MB"] > 256
     f = legs["random_fused_262144_boards"]
     assert f["bound"] == "valu" and f["steps_per_launch"] == 64 and f["us_per_step"] < legs["config3_262144_boards"]["us_per_step"]
     assert 0.3 < f["issue_frac"] < 1.0 and 0.5 < legs["random_fused_1048576_boards"]["issue_frac"] < 1.05
+
+
+def test_bench_line_survives_a_failing_returns_gather():
+    """the gather of per-board returns is optional bookkeeping; when it raises (here: injected on
+    both ranks) the line still prints, rc 0, with the scaling value intact and the error inside it.  And
+    QTTT_BENCH_NO_GATHER=1 skips it."""
+    common = ("--gpus", "2", "--boards", "32768", "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    d = run_bench(*common, env={"QTTT_DIST_BACKEND": "gloo", "QTTT_BENCH_FAIL_GATHER": "1"})
+    assert d["n_gpus"] == 2 == d["ranks_seen"] and d["value"] > 0 and d["config"]["replay_matches_recording"] is True
+    assert "injected failure" in d["returns_gather"]["error"] and "ms" not in d["returns_gather"]
+    assert abs(d["value"] - 2 * 32768 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    e = run_bench(*common, env={"QTTT_DIST_BACKEND": "gloo", "QTTT_BENCH_NO_GATHER": "1"})
+    assert e["returns_gather"] == {"skipped": "QTTT_BENCH_NO_GATHER=1"} and e["ranks_seen"] == 2
 
 
 def test_bench_total_boards_is_strong_scaling():

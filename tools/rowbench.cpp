@@ -141,23 +141,61 @@ int main(int argc, char **argv) {
     vs.push_back({"export_floor<" #BLK "," #BPL ">", [=](hipStream_t st) {                                               \
         hipLaunchKernelGGL((export_floor<BLK, BPL>), dim3((unsigned)((n + BLK * BPL - 1) / (BLK * BPL))), dim3(BLK), 0, st, p.P, p.Q, eo, n); }, {}});
     EXPV(256, 1) EXPV(512, 1) EXPV(1024, 1) EXPV(256, 2) EXPV(512, 2) EXPV(1024, 2)
+    u64 *skey; CK(hipMalloc(&skey, n * 8));
 #define NIV(BLK)                                                                                                         \
-    vs.push_back({"node_info<" #BLK ">", [=](hipStream_t st) {                                                           \
-        hipLaunchKernelGGL((node_info_kernel<BLK>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,   \
-                           p.P, p.Q, winner, terminal, legal, key, n); }, {}});                                         \
-    vs.push_back({"node_info<" #BLK "> without key", [=](hipStream_t st) {                                               \
-        hipLaunchKernelGGL((node_info_kernel<BLK>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,   \
-                           p.P, p.Q, winner, terminal, legal, (int64_t *)nullptr, n); }, {}});
+    vs.push_back({"node_info<" #BLK "> CPython key + native key", [=](hipStream_t st) {                                  \
+        hipLaunchKernelGGL((node_info_kernel<BLK, true>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,   \
+                           p.P, p.Q, winner, terminal, legal, key, skey, n); }, {}});                                   \
+    vs.push_back({"node_info<" #BLK "> native key", [=](hipStream_t st) {                                                \
+        hipLaunchKernelGGL((node_info_kernel<BLK, false>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,  \
+                           p.P, p.Q, winner, terminal, legal, (int64_t *)nullptr, skey, n); }, {}});                    \
+    vs.push_back({"node_info<" #BLK "> no key", [=](hipStream_t st) {                                                    \
+        hipLaunchKernelGGL((node_info_kernel<BLK, false>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,  \
+                           p.P, p.Q, winner, terminal, legal, (int64_t *)nullptr, (u64 *)nullptr, n); }, {}});          \
+    vs.push_back({"node_info<" #BLK "> native key alone", [=](hipStream_t st) {                                          \
+        hipLaunchKernelGGL((node_info_kernel<BLK, false>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,  \
+                           p.P, p.Q, (int8_t *)nullptr, (uint8_t *)nullptr, (u64 *)nullptr, (int64_t *)nullptr, skey, n); }, {}});
     NIV(256) NIV(512) NIV(1024)
-    uint8_t *act36, *nch; u64 *kid0, *kid1; int8_t *w2; uint8_t *t2; u64 *l2; int64_t *k2;
-    CK(hipMalloc(&act36, n)); CK(hipMemset(act36, 7, n)); CK(hipMalloc(&nch, n)); CK(hipMalloc(&kid0, s64 * 16)); CK(hipMalloc(&kid1, s64 * 16));
+    uint8_t *act36, *nch; u64 *kid0, *kid1; int8_t *w2; uint8_t *t2; u64 *l2; int64_t *k2; u64 *sk2; int32_t *vsum;
+    CK(hipMalloc(&act36, n));
+    { std::vector<uint8_t> ha(n); u32 x = 12345u; for (auto &v : ha) { x = x * 1664525u + 1013904223u; v = (uint8_t)((x >> 16) % 36u); }
+      CK(hipMemcpy(act36, ha.data(), n, hipMemcpyHostToDevice)); } CK(hipMalloc(&nch, n)); CK(hipMalloc(&kid0, s64 * 16)); CK(hipMalloc(&kid1, s64 * 16));
     CK(hipMalloc(&w2, 2 * n)); CK(hipMalloc(&t2, 2 * n)); CK(hipMalloc(&l2, 16 * n)); CK(hipMalloc(&k2, 16 * n));
+    CK(hipMalloc(&sk2, 16 * n)); CK(hipMalloc(&vsum, 8 * n));
     Planes c0 = planes(kid0, n), c1 = planes(kid1, n);
+    const ExpandOut xo_py = {nch, w2, t2, l2, k2, sk2}, xo = {nch, w2, t2, l2, nullptr, sk2}, xo_lean = {nch, w2, t2, nullptr, nullptr, sk2};
 #define EXV(BLK)                                                                                                         \
-    vs.push_back({"expand<" #BLK "> (action 7 everywhere)", [=](hipStream_t st) {                                        \
-        hipLaunchKernelGGL((expand_kernel<BLK>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, st, p.P, p.Q, act36, \
-                           c0.P, c0.Q, c1.P, c1.Q, nch, w2, t2, l2, k2, n); }, {}});
+    vs.push_back({"expand<" #BLK "> CPython + native keys (uniform random actions)", [=](hipStream_t st) {                \
+        hipLaunchKernelGGL((expand_kernel<BLK, true>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, st, p.P, p.Q, act36, \
+                           c0.P, c0.Q, c1.P, c1.Q, xo_py, n); }, {}});                                                   \
+    vs.push_back({"expand<" #BLK "> native keys", [=](hipStream_t st) {                                                   \
+        hipLaunchKernelGGL((expand_kernel<BLK, false>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, st, p.P, p.Q, act36, \
+                           c0.P, c0.Q, c1.P, c1.Q, xo, n); }, {}});                                                      \
+    vs.push_back({"expand<" #BLK "> native keys, no legal masks", [=](hipStream_t st) {                                   \
+        hipLaunchKernelGGL((expand_kernel<BLK, false>), dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, st, p.P, p.Q, act36, \
+                           c0.P, c0.Q, c1.P, c1.Q, xo_lean, n); }, {}});
     EXV(256) EXV(512) EXV(1024)
+#define XRV(SIMS)                                                                                                        \
+    vs.push_back({"expand_rollout<256> " #SIMS " playouts per child, native keys", [=](hipStream_t st) {                  \
+        const u32 ppb = 256u / (2u * SIMS);                                                                              \
+        hipLaunchKernelGGL((expand_rollout_kernel<256, false>), dim3((unsigned)((n + ppb - 1) / ppb)), dim3(256), 0, st, p.P, p.Q, act36, \
+                           c0.P, c0.Q, c1.P, c1.Q, xo, (u64)5, 0u, (u64)0, (u32)SIMS, ppb, vsum, (int8_t *)nullptr, n); }, {}});
+#define XJV(SIMS, PPB)                                                                                                   \
+    vs.push_back({"expand_rollout_jobs<256> " #SIMS " playouts per child, " #PPB " pairs per workgroup", [=](hipStream_t st) { \
+        hipLaunchKernelGGL((expand_rollout_jobs_kernel<256, false>), dim3((unsigned)((n + PPB - 1) / PPB)), dim3(256), 0, st, p.P, p.Q, act36, \
+                           c0.P, c0.Q, c1.P, c1.Q, xo, (u64)5, 0u, (u64)0, (u32)SIMS, (u32)PPB, vsum, (int8_t *)nullptr, n); }, {}});
+    XRV(1) XRV(10)
+    XJV(1, 32) XJV(1, 64) XJV(1, 128) XJV(1, 256) XJV(10, 16) XJV(10, 32) XJV(10, 64) XJV(10, 128) XJV(10, 256)
+    // the playouts alone, for comparison: rollout_many on the parents (what round 3's unit did) and on child 0
+    {
+        int8_t *rres; CK(hipMalloc(&rres, n * 10));
+        vs.push_back({"rollout_many<512> 10 playouts per PARENT", [=](hipStream_t st) {
+            hipLaunchKernelGGL(rollout_many_kernel, dim3((unsigned)((n * 10 + 511) / 512)), dim3(512), 0, st, p.P, p.Q, (u64)5, 0u, (u64)0, 10u,
+                               rres, (uint8_t *)nullptr, n * 10); }, {}});
+        vs.push_back({"rollout_many<512> 10 playouts per child 0 (of the last expand)", [=](hipStream_t st) {
+            hipLaunchKernelGGL(rollout_many_kernel, dim3((unsigned)((n * 10 + 511) / 512)), dim3(512), 0, st, c0.P, c0.Q, (u64)5, 0u, (u64)0, 10u,
+                               rres, (uint8_t *)nullptr, n * 10); }, {}});
+    }
     ObsOut oo;
     CK(hipMalloc(&oo.classical, n * 9)); CK(hipMalloc(&oo.q_p1, n * 10)); CK(hipMalloc(&oo.q_p1_len, n));
     CK(hipMalloc(&oo.q_p2, n * 8)); CK(hipMalloc(&oo.q_p2_len, n)); CK(hipMalloc(&oo.turn, n));

@@ -112,6 +112,7 @@ struct Lib {
     int (*step_wpb)(void *, const uint8_t *, const uint8_t *, uint64_t, uint32_t, int64_t, uint32_t, float *, uint8_t *, int64_t, void *);
     int (*step_obs)(void *, const uint8_t *, const uint8_t *, uint64_t, uint32_t, int64_t, uint32_t, float *, uint8_t *, int8_t *,
                     uint8_t *, uint8_t *, uint8_t *, uint8_t *, uint8_t *, int64_t, void *);
+    int (*step_random)(void *, uint64_t, uint32_t, int64_t, uint32_t, uint8_t *, float *, uint8_t *, int64_t, void *);
     std::vector<float> us;
 };
 
@@ -138,6 +139,7 @@ int main(int argc, char **argv) {
                 *(void **)(&L.step_wpb) = dlsym(hs, "qttt_step_wave_per_board");
         }
         *(void **)(&L.step_obs) = dlsym(L.h, "qttt_step_observe");          // optional (STEPBENCH_OBS=1 times it)
+        *(void **)(&L.step_random) = dlsym(L.h, "qttt_step_random");        // optional (STEPBENCH_RANDOM=1 times it)
         libs.push_back(L);
     }
     void *state; uint8_t *actions, *term; float *reward;
@@ -148,6 +150,8 @@ int main(int argc, char **argv) {
     hipStream_t s; CK(hipStreamCreate(&s));
     // STEPBENCH_OBS=1: time qttt_step_observe (step + observation, one kernel) instead of qttt_step
     const bool obs_mode = getenv("STEPBENCH_OBS") != nullptr;
+    // STEPBENCH_RANDOM=1: time qttt_step_random (policy + step in one kernel, the actions played written out)
+    const bool random_mode = getenv("STEPBENCH_RANDOM") != nullptr;
     int8_t *o_cl; uint8_t *o_p1, *o_l1, *o_p2, *o_l2, *o_tn;
     CK(hipMalloc(&o_cl, n * 9)); CK(hipMalloc(&o_p1, n * 10)); CK(hipMalloc(&o_l1, n)); CK(hipMalloc(&o_p2, n * 8));
     CK(hipMalloc(&o_l2, n)); CK(hipMalloc(&o_tn, n));
@@ -174,6 +178,9 @@ int main(int argc, char **argv) {
                 for (int t = 0; t < K && !rc; ++t)
                     rc = L.step_obs(state, actions + (size_t)(W + t) * 2 * n, nullptr, seed, W + t, 0, 1, reward, term, o_cl, o_p1,
                                     o_l1, o_p2, o_l2, o_tn, n, s);
+            } else if (random_mode && L.step_random) {
+                for (int t = 0; t < K && !rc; ++t)
+                    rc = L.step_random(state, seed, W + t, 0, 1, actions + (size_t)(W + t) * 2 * n, reward, term, n, s);
             } else {
                 rc = L.step_many(state, actions + (size_t)W * 2 * n, nullptr, seed, W, 0, 1, reward, term, 0, n, K, s);
             }
