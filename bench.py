@@ -237,6 +237,9 @@ def median(xs):
     return s[m] if len(s) & 1 else 0.5 * (s[m - 1] + s[m])
 
 
+GRAPH_LAUNCHES = 100
+
+
 def time_calls(torch, dev, fn, K, regions):
     """us per call of `fn` (a VecEnv method with reused buffers), two ways, both by HIP events on the launch stream:
     eager — K Python calls per region: below ~6 us per kernel this is the HOST's rate (ctypes + hipLaunchKernel), not
@@ -256,10 +259,11 @@ def time_calls(torch, dev, fn, K, regions):
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
+    G = max(K, GRAPH_LAUNCHES)                      # a replay costs ~10 - 20 us of its own: spread it over many launches
     with torch.cuda.stream(side):
         fn()
         with torch.cuda.graph(graph, stream=side):
-            for _ in range(K):
+            for _ in range(G):
                 fn()
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize(dev)
@@ -270,7 +274,7 @@ def time_calls(torch, dev, fn, K, regions):
         graph.replay()
         e1.record()
         torch.cuda.synchronize(dev)
-        dev_paced.append(e0.elapsed_time(e1) * 1e3 / K)
+        dev_paced.append(e0.elapsed_time(e1) * 1e3 / G)
     return dev_paced, eager
 
 
@@ -478,7 +482,7 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
         u = median(us)
         out.append({"name": "row_%s_1048576_boards" % name, "boards": n, "mode": "row", "kernel": kernel, "steps": K,
                     "regions": regions, "us_per_launch": u, "best_region_us_per_launch": min(us),
-                    "timing": "hipGraph of %d launches replayed (device-paced); us_per_python_call = the same calls eager" % K,
+                    "timing": "hipGraph of %d launches replayed (device-paced); us_per_python_call = the same calls eager" % max(K, GRAPH_LAUNCHES),
                     "us_per_python_call": median(us_eager),
                     "algorithmic_bytes_per_board": algo, "achieved_GBps": algo * n / (u * 1e-6) / 1e9,
                     "frac": algo * n / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": bound})
@@ -521,13 +525,15 @@ def config5_leg(torch, dev, args, n=65536, K=50):
     algo = sb + 1 + 2 * sb + 1 + 2 * (1 + 1 + 8 + 8 + 4)
     u = median(us1)
     return {"name": "config5_expand_rollout_65536_pairs", "boards": n, "mode": "mcts-unit",
-            "kernel": "expand_rollout_kernel<256, false>", "steps": K, "regions": len(us1),
+            "kernel": "expand_rollout_kernel<256, false> (one playout per child: a lane per (pair, simulation, child)); "
+                      "expand_rollout_jobs_kernel<256, false> (ten: the children that exist dealt to the lanes)",
+            "steps": K, "regions": len(us1),
             "us_per_unit": u, "best_region_us_per_unit": min(us1), "expansions_per_s": n / (u * 1e-6),
             "us_per_unit_with_10_playouts_per_leaf": median(us10),
             "playouts_per_s_10_per_leaf": 10 * float((x10["n_children"].to(torch.int64)).sum()) / (median(us10) * 1e-6),
             "children_per_pair": float(x10["n_children"].to(torch.float32).mean()),
             "us_per_unit_as_three_launches": median(us1_3), "us_per_unit_as_three_launches_10_playouts": median(us10_3),
-            "timing": "hipGraph of %d units replayed (device-paced); *_python_call = the same calls eager" % K,
+            "timing": "hipGraph of %d units replayed (device-paced); *_python_call = the same calls eager" % max(K, GRAPH_LAUNCHES),
             "us_per_unit_python_call": median(us1_eager), "us_per_unit_with_10_playouts_python_call": median(us10_eager),
             "us_per_unit_as_three_launches_python_calls": median(us1_3_eager),
             "us_per_unit_as_three_launches_10_playouts_python_calls": median(us10_3_eager),

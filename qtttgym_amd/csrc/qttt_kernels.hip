@@ -512,11 +512,12 @@ int qttt_expand(const void *state, const uint8_t *action36, void *child0, void *
     if (expand_rows_misaligned(winner, terminal, legal, key, state_key)) return QTTT_ERR_ACTION;
     Planes p = planes(const_cast<void *>(state), n), c0 = planes(child0, n), c1 = planes(child1, n);
     const ExpandOut o = {n_children, winner, terminal, (u64 *)legal, key, (u64 *)state_key};
-    // 256-thread workgroups at every batch size (tools/rowbench, 1 M pairs with native keys: 19.1 us against 20.3 with
-    // 1024 threads; 64 K pairs: 4.4 against 4.9); with the CPython keys the two are level (29.4)
-#define QTTT_EX(PK) hipLaunchKernelGGL((expand_kernel<256, PK>), dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, \
-                                       p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, n)
-    if (key) QTTT_EX(true); else QTTT_EX(false);
+    // workgroup size by batch (tools/rowbench, us per launch, 256 / 512 / 1024 threads: 1 M pairs with native keys 18.3 /
+    // 18.2 / 17.5, with the CPython keys 28.3 / 26.8 / 25.0; 64 K pairs 4.5 / 4.4 / 4.7 and 5.8 / 6.1 / 7.7)
+#define QTTT_EX(BLK, PK) hipLaunchKernelGGL((expand_kernel<BLK, PK>), dim3(blocks_for(n, BLK)), dim3(BLK), 0, (hipStream_t)stream, \
+                                            p.P, p.Q, action36, c0.P, c0.Q, c1.P, c1.Q, o, n)
+    if (n >= 384 * 1024) { if (key) QTTT_EX(1024, true); else QTTT_EX(1024, false); }
+    else                 { if (key) QTTT_EX(256, true);  else QTTT_EX(256, false); }
 #undef QTTT_EX
     return launch_status();
 }
@@ -542,9 +543,14 @@ int qttt_expand_rollout(const void *state, const uint8_t *action36, void *child0
     // least ~1 000 workgroups so that a small batch still covers the chip.
     const int64_t playouts = n * (int64_t)n_sims;
     if (playouts >= 262144) {
-        int64_t P = n / 1024;
-        if (P > XR_MAX_PAIRS) P = XR_MAX_PAIRS;
-        if (P < 8) P = 8;
+        // P pairs per workgroup: a power of two (the workgroups' rows of every output then start on whole cache lines),
+        // at most one pair per lane, and few enough that ~1 000 workgroups exist.  tools/rowbench, us per launch, 10
+        // playouts per child: 65 536 pairs P = 32 / 48 / 58 / 64 / 128 / 256 -> 25.9 / 26.2 / 26.7 / 24.9 / 26.9 / 37.7;
+        // 1 M pairs 64 / 128 / 251 / 256 -> 194 / 180 / 180 / 175 (one playout per child: 128 / 193 / 256 -> 46.7 / 39.9 /
+        // 37.3).  Filling the workgroup's last round of lanes (P = 58: 708 jobs = 2.8 rounds instead of 3.05) does not
+        // pay: the chip is bound by the total of wave-rounds, not by a workgroup's own span.
+        int64_t P = 8;
+        while (P * 2 <= XR_MAX_PAIRS && P * 2 * 1024 <= n) P *= 2;
         const u32 ppb = (u32)P;
         const unsigned grid = (unsigned)((n + ppb - 1) / ppb);
 #define QTTT_XJ(PK) hipLaunchKernelGGL((expand_rollout_jobs_kernel<BLK, PK>), dim3(grid), dim3(BLK), 0, (hipStream_t)stream,  \

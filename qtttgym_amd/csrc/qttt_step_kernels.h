@@ -39,9 +39,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     u32 last_groups, StepKeySource<DEVSTEP> sk) {
     constexpr u32 TILE_BOARDS = BLOCK * BPL;
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
-    // the policy's tables (qttt_state.h PolicyRows: one word per empty-square mask + the pre-scaled pair table)
-    constexpr int PRW = SAMPLE ? (int)((POLICY_ROWS_WORDS + BLOCK - 1) / BLOCK) : 1;
-    __shared__ __attribute__((aligned(16))) u32 prows[SAMPLE ? POLICY_ROWS_WORDS : 1];
+    // the policy's tables: from 512 threads up qttt_state.h's PolicyRows (one word per empty-square mask + the
+    // pre-scaled pair table, 692 words), in 256-thread workgroups — where that would be three table words per thread —
+    // the two-level PolicyLut (146 words).  tools/stepbench STEPBENCH_RANDOM=1, interleaved, us per launch, round 3's
+    // kernel / trusted step + two-level table / trusted step + rows: 1 M boards (2 x 1024) 8.06 / 7.79 / 7.66,
+    // 768 K (2 x 512) 6.69 / 6.43 / 6.45, 2 M (2 x 256) 15.03 / 14.80 / 15.16, 256 K (1 x 256) 4.13 / 3.75 / 3.88.
+    constexpr bool ROWS = SAMPLE && BLOCK >= 512;
+    constexpr u32 PT_WORDS = ROWS ? POLICY_ROWS_WORDS : POLICY_LUT_WORDS;
+    constexpr int PRW = SAMPLE ? (int)((PT_WORDS + BLOCK - 1) / BLOCK) : 1;
+    __shared__ __attribute__((aligned(16))) u32 prows[SAMPLE ? PT_WORDS : 1];
     __shared__ __attribute__((aligned(16))) uint8_t otile[OBS ? obs_lds_bytes(TILE_BOARDS) : 16];
     __shared__ __attribute__((aligned(16))) u32 olut[OBS ? OBS_LUT_BYTES / 4 : 4];
 #ifdef QTTT_DEBUG_STAMPS
@@ -73,7 +79,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
 #pragma unroll
         for (int k = 0; k < PRW; ++k) {
             const u32 w = threadIdx.x + (u32)k * BLOCK;
-            prw[k] = w < POLICY_ROWS_WORDS ? reinterpret_cast<const u32 *>(&g_policy_rows)[w] : 0u;
+            const u32 *src = ROWS ? reinterpret_cast<const u32 *>(&g_policy_rows) : reinterpret_cast<const u32 *>(&g_policy_lut);
+            prw[k] = w < PT_WORDS ? src[w] : 0u;
         }
     }
     V64 p = load_stream(&reinterpret_cast<const V64 *>(pP + ib)[g]);
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
 #pragma unroll
         for (int k = 0; k < PRW; ++k) {
             const u32 w = threadIdx.x + (u32)k * BLOCK;
-            if (w < POLICY_ROWS_WORDS) prows[w] = prw[k];
+            if (w < PT_WORDS) prows[w] = prw[k];
         }
     }
     ObsTiles T;
@@ -115,19 +122,17 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
                     // a finished board restarts first (empty = all zero); a board that is not done has >= 2 empty
                     // squares (8 classical squares set the done bit), so the policy always finds a legal pair,
                     // lo < hi by construction: the step runs TRUSTED (no validation, no sorting), as in
-                    // step_random_fused_kernel.  A/B, interleaved (tools/stepbench STEPBENCH_RANDOM=1, 1 M boards, us per
-                    // launch): round 3's two-level lookup + validated step 8.08; trusted step alone 7.84; the 4.5 KB
-                    // byte table of the fused stepper 7.67 (but 15.6 against 14.9 in 256-thread workgroups: 4.5 table
-                    // words per thread)
+                    // step_random_fused_kernel
                     const u32 keep = ~(u32)((int)P1 >> 31);
                     P0 &= keep; P1 &= keep; Q0 &= keep; Q1 &= keep;
                     const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
-                    av = policy_action_rows(prows, empty, h2);
+                    av = ROWS ? policy_action_rows(prows, empty, h2) : policy_action(reinterpret_cast<const uint8_t *>(prows), empty, h2);
                     win = step_core<false, true>(P0, P1, Q0, Q1, av, bit, lut);
                 } else {
                     // post-terminal legal moves are accepted; no legal pair -> (0,0), a noop
                     const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
-                    av = (empty & (empty - 1u)) ? policy_action_rows(prows, empty, h2) : 0u;
+                    av = !(empty & (empty - 1u)) ? 0u : ROWS ? policy_action_rows(prows, empty, h2)
+                                                             : policy_action(reinterpret_cast<const uint8_t *>(prows), empty, h2);
                     win = step_core<false>(P0, P1, Q0, Q1, av, bit, lut);
                 }
                 act.v[k] = (uint16_t)av;

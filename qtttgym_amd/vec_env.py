@@ -467,22 +467,21 @@ class VecEnv:
         position key: equal <=> equal (board, moves); qttt_state_key of the packed words) and — with
         python_key — key int64 = Python's hash(tuple(board)+tuple(moves)), for host-side dicts built by
         reference code (three quarters of the kernel's work: a device-side search passes python_key=False).
-        `out` = the dict of an earlier call, to be overwritten (its "key" entry decides python_key)."""
+        `out` = the dict of an earlier call, to be overwritten: only the entries it holds are computed."""
         n, dev = self.num_envs, self.device
-        spec = (("winner", torch.int8), ("terminal", torch.bool), ("legal", torch.int64), ("state_key", torch.int64))
+        spec = (("winner", torch.int8), ("terminal", torch.bool), ("legal", torch.int64), ("state_key", torch.int64),
+                ("key", torch.int64))
         if out is None:
             with torch.cuda.device(dev):
-                out = {k: torch.empty(n, dtype=dt, device=dev) for k, dt in spec}
-                if python_key:
-                    out["key"] = torch.empty(n, dtype=torch.int64, device=dev)
-        else:
-            for k, dt in spec + ((("key", torch.int64),) if "key" in out else ()):
-                t = out[k]
-                if t.dtype != dt or t.numel() != n or not t.is_contiguous() or t.device != self.state.device:
+                out = {k: torch.empty(n, dtype=dt, device=dev) for k, dt in spec if k != "key" or python_key}
+        else:                                       # every entry is optional: only what the dict holds is computed
+            for k, dt in spec:
+                t = out.get(k)
+                if t is not None and (t.dtype != dt or t.numel() != n or not t.is_contiguous() or t.device != self.state.device):
                     raise ValueError("out[%r] must be a contiguous %s device tensor of N elements" % (k, dt))
-        rc = self._launch(self._lib.qttt_node_info, self.state.data_ptr(), out["winner"].data_ptr(),
-                          out["terminal"].data_ptr(), out["legal"].data_ptr(), _ptr(out.get("key")),
-                          out["state_key"].data_ptr(), n, self._stream())
+        rc = self._launch(self._lib.qttt_node_info, self.state.data_ptr(), _ptr(out.get("winner")),
+                          _ptr(out.get("terminal")), _ptr(out.get("legal")), _ptr(out.get("key")),
+                          _ptr(out.get("state_key")), n, self._stream())
         _native.check(rc, "qttt_node_info")
         return out
 
@@ -513,13 +512,15 @@ class VecEnv:
                     out[k] = torch.empty((n,) + shp, dtype=dt, device=dev)
                 if python_key:
                     out["key"] = torch.empty((n, 2), dtype=torch.int64, device=dev)
-        else:
+        else:                                       # the per-child rows are optional: only what the dict holds is computed
             sd = self.state.device
             for c in ("child0", "child1"):
                 if out[c].num_envs != n or out[c].state.device != sd:
                     raise ValueError("out[%r] must be a VecEnv of N boards on this device" % c)
-            for k, dt, shp in self._EXPAND_ROWS + tuple(extra) + ((("key", torch.int64, (2,)),) if "key" in out else ()):
-                _check_out(out[k], dt, (n,) + shp, sd, "out[%r]" % k)
+            required = tuple(k for k, _, _ in extra)
+            for k, dt, shp in self._EXPAND_ROWS + tuple(extra) + (("key", torch.int64, (2,)),):
+                if k in out or k in required:
+                    _check_out(out[k], dt, (n,) + shp, sd, "out[%r]" % k)
         return out
 
     def _as_action36(self, action36):
@@ -541,9 +542,9 @@ class VecEnv:
         a = self._as_action36(action36)
         out = self._expand_out(out, python_key)
         rc = self._launch(self._lib.qttt_expand, self.state.data_ptr(), a.data_ptr(), out["child0"].state.data_ptr(),
-                          out["child1"].state.data_ptr(), out["n_children"].data_ptr(), out["winner"].data_ptr(),
-                          out["terminal"].data_ptr(), out["legal"].data_ptr(), _ptr(out.get("key")),
-                          out["state_key"].data_ptr(), n, self._stream())
+                          out["child1"].state.data_ptr(), _ptr(out.get("n_children")), _ptr(out.get("winner")),
+                          _ptr(out.get("terminal")), _ptr(out.get("legal")), _ptr(out.get("key")),
+                          _ptr(out.get("state_key")), n, self._stream())
         _native.check(rc, "qttt_expand")
         return out
 
@@ -565,9 +566,9 @@ class VecEnv:
         extra = (("value_sum", torch.int32, (2,)),) + ((("result", torch.int8, (2, S)),) if with_result else ())
         out = self._expand_out(out, python_key, extra)
         rc = self._launch(self._lib.qttt_expand_rollout, self.state.data_ptr(), a.data_ptr(),
-                          out["child0"].state.data_ptr(), out["child1"].state.data_ptr(), out["n_children"].data_ptr(),
-                          out["winner"].data_ptr(), out["terminal"].data_ptr(), out["legal"].data_ptr(),
-                          _ptr(out.get("key")), out["state_key"].data_ptr(), self.seed, int(step_idx0), self.board_offset,
+                          out["child0"].state.data_ptr(), out["child1"].state.data_ptr(), _ptr(out.get("n_children")),
+                          _ptr(out.get("winner")), _ptr(out.get("terminal")), _ptr(out.get("legal")),
+                          _ptr(out.get("key")), _ptr(out.get("state_key")), self.seed, int(step_idx0), self.board_offset,
                           S, out["value_sum"].data_ptr(), _ptr(out.get("result")), n, self._stream())
         _native.check(rc, "qttt_expand_rollout")
         return out

@@ -185,7 +185,7 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL((expand_rollout_jobs_kernel<256, false>), dim3((unsigned)((n + PPB - 1) / PPB)), dim3(256), 0, st, p.P, p.Q, act36, \
                            c0.P, c0.Q, c1.P, c1.Q, xo, (u64)5, 0u, (u64)0, (u32)SIMS, (u32)PPB, vsum, (int8_t *)nullptr, n); }, {}});
     XRV(1) XRV(10)
-    XJV(1, 32) XJV(1, 64) XJV(1, 128) XJV(1, 256) XJV(10, 16) XJV(10, 32) XJV(10, 64) XJV(10, 128) XJV(10, 256)
+    XJV(1, 64) XJV(1, 128) XJV(1, 193) XJV(1, 256) XJV(10, 32) XJV(10, 48) XJV(10, 58) XJV(10, 64) XJV(10, 128) XJV(10, 251) XJV(10, 256)
     // the playouts alone, for comparison: rollout_many on the parents (what round 3's unit did) and on child 0
     {
         int8_t *rres; CK(hipMalloc(&rres, n * 10));
