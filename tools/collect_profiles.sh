@@ -21,20 +21,10 @@ cp "$P"/kt_full/runc/*_kernel_stats.csv "$O/kernel_stats_default_command_with_le
 cp "$P"/kt16/runc/*_kernel_stats.csv "$O/kernel_stats_16M_boards.csv"
 cp "$P"/kt_gym/runc/*_kernel_stats.csv "$O/kernel_stats_gym.csv"
 cp "$P"/kt_fused/runc/*_kernel_stats.csv "$O/kernel_stats_random_fused_262144.csv"
-[ -d "$P/kt_rows" ] && python3 tools/trace_rows_summary.py "$P/kt_rows" > "$O/kernel_trace_rows.csv"
+[ -f "$P/kernel_trace_rows.csv" ] && cp "$P/kernel_trace_rows.csv" "$O/kernel_trace_rows.csv"
 for n in kt kt_full kt16 kt_gym kt_fused; do grep "^{" "$P/$n.log" > "$O/bench_${n}_under_rocprof.json"; done
-python3 tools/pmc_summary.py 1048576 "$P/pmc_f" "$P/pmc_w" "$(basename "$O") step_kernel<1024,2,false,true,false,false> via bench.py --steps 20 --warmup 5 --regions 3 --no-legs" 16 > /dev/null
-python3 tools/pmc_summary.py 16777216 "$P/pmc_f16" "$P/pmc_w16" "$(basename "$O") step_kernel<256,2,false,true,false,false> via bench.py --boards 16777216 --steps 10 --warmup 2 --regions 2 --no-legs" 16 > /dev/null
-for n in pmc_f pmc_w pmc_f16 pmc_w16; do python3 - "$P/$n" "$O/${n}_step_kernel_counter_collection.csv" <<'PY'
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"]]
-w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows[-48:])
-PY
-done
-python3 tools/pmc_sq_summary.py "$P/pmc_sq" 1048576 > "$O/pmc_sq_summary.csv"
-python3 tools/pmc_sq_summary.py "$P/pmc_sq_fused" 1048576 > "$O/pmc_sq_fused_summary.csv"
-python3 tools/pmc_sq_summary.py "$P/pmc_sq_rows" 1048576 > "$O/pmc_sq_rows_summary.csv"
+cp "$P/pmc_traffic.json" profiles/pmc_traffic.json
+cp "$P"/pmc_*_step_kernel_counter_collection.csv "$P"/pmc_sq_summary.csv "$P"/pmc_sq_fused_summary.csv "$P"/pmc_sq_rows_summary.csv "$O/"
 for f in "$N"/bench_*.json rows.jsonl stepbench_262144.txt rowbench_1M.txt rowbench_64K.txt nproc.txt; do
   [ -f "$f" ] && cp "$f" "$O/" || cp "$N/$f" "$O/"
 done
