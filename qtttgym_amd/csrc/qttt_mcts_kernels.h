@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
     const int64_t il = valid ? i : 0;
     const u64 P = pP[il], Q = pQ[il];
     const u32 a = (u32)action36[il];
-    if (t < XR_MAX_PAIRS * 2) acc[t] = 0;
+    for (u32 k = t; k < 2u * XR_MAX_PAIRS; k += BLOCK) acc[k] = 0;
     fill_policy_lut<BLOCK>(plut);
     fill_nth9<BLOCK>(nth9);
     if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
@@ -432,9 +432,9 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
         if (result) result[(ip * 2 + child) * (int64_t)n_sims + sim] = (int8_t)r;
     }
     __syncthreads();
-    if (t < 2u * pairs_per_block) {
-        const int64_t o = base * 2 + t;
-        if (o < 2 * n) value_sum[o] = acc[t];
+    for (u32 k = t; k < 2u * pairs_per_block; k += BLOCK) {     // (with one pair per lane there are two sums per lane)
+        const int64_t o = base * 2 + k;
+        if (o < 2 * n) value_sum[o] = acc[k];
     }
 }
 

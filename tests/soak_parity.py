@@ -67,6 +67,10 @@ def one_case(rng, k):
         bits = torch.from_numpy(bits_np).to(env.device) if use_bits else None
         if observe:
             o, reward, term = env.step_observe_raw(a, bits)
+        elif not adversarial and not use_bits and t % 3 == 2:      # policy + step in one kernel: the same step
+            played = torch.empty_like(a)
+            reward, term = env.step_random(actions_out=played)
+            assert torch.equal(played, a), ("step_random actions", t)
         else:
             reward, term = env.step_raw(a, bits)
         r_or, t_or = ob.step(a_or, bits_np, seed, t, off, auto_reset)
@@ -126,7 +130,37 @@ def rows_case(rng, k):
     assert np.array_equal(npy(result), res_o) and np.array_equal(npy(plies), plies_o)
     exf = {kk: npy(v) for kk, v in final.export_boards().items()}
     assert np.array_equal(exf["board"], fin_o.board) and np.array_equal(exf["moves"], fin_o.moves)
-    return dict(case=k, rows=True, n=n, offset=off)
+    # ---- round 4: the packed state is canonical (import of the export is the state, bit for bit) ...
+    exb = env.export_boards()
+    back = VecEnv(n, seed=seed, board_offset=off)
+    back.import_boards(exb["moves"], exb["n_moves"], exb["board"], exb["qmask"], exb["n_q"])
+    pl = lambda e: e.state.view(torch.int64).view(2, -1)[:, :n]
+    assert torch.equal(pl(back), pl(env)), "import(export(s)) != s"
+    # ... so the native key is equal exactly where the oracle's CPython hash is, for the parents and all children
+    nat = [npy(info["state_key"])] + [npy(out["state_key"])[nch > c, c] for c in range(2)]
+    pyk = [key] + [k2[nch > c, c] for c in range(2)]
+    nat, pyk = np.concatenate(nat), np.concatenate(pyk)
+    assert len(np.unique(np.stack([nat, pyk], 1), axis=0)) == len(np.unique(nat)) == len(np.unique(pyk)), "key partition"
+    # ---- qttt_expand_rollout (either mapping, by size) against the oracle's expand + playout loop
+    S = int(rng.choice([1, 2, 5, 10])) if n <= 4099 else 1
+    xr = env.expand_rollout(torch.from_numpy(act), n_sims=S, step_idx0=s0, with_result=True, python_key=True)
+    assert np.array_equal(npy(xr["n_children"]), nch) and torch.equal(xr["state_key"], out["state_key"])
+    assert torch.equal(xr["key"], out["key"]) and torch.equal(xr["winner"], out["winner"]) and torch.equal(xr["legal"], out["legal"])
+    res, vs = npy(xr["result"]), npy(xr["value_sum"])
+    for c in range(2):
+        sel = nch > c
+        tot = np.zeros(n, dtype=np.int64)
+        for sim in range(S):
+            r_o, _, _ = oracle.rollout(kids[c], seed, s0 + (c * S + sim) * 16, off)
+            assert np.array_equal(res[sel, c, sim], r_o[sel]), ("expand_rollout result", c, sim)
+            tot += r_o
+        # leaf.turn (mcts.py:174,243): True after an even number of real moves (an autofill move is not one)
+        mv, nm = kids[c].moves, kids[c].n_moves.astype(np.int64)
+        last = mv[np.arange(n), np.maximum(nm - 1, 0)]
+        real = nm - ((nm > 0) & (last[:, 0] == last[:, 1]))
+        assert np.array_equal(vs[sel, c], np.where(real % 2 == 0, tot, -tot)[sel]), ("value_sum", c)
+        assert (res[~sel, c] == 0).all() and (vs[~sel, c] == 0).all()
+    return dict(case=k, rows=True, n=n, offset=off, sims=S)
 
 
 def main():
