@@ -44,6 +44,7 @@ SIGNATURES = {
     "qttt_import": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_board_op": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_board_op_sync": (_i32, [_vp, _vp, _i64, _vp]),
+    "qttt_board_op_host": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
     "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_state_key": (_u64, [_u64, _u64]),

@@ -63,7 +63,7 @@ class _Staging:
                                           "Board runs its rules in libqttt_hip.so, there is no CPU path")
         self.lib = _native.lib()
         self.lock = threading.Lock()
-        self.op_sync = self.lib.qttt_board_op_sync
+        self.op_sync = self.lib.qttt_board_op_host         # pinned records: poll the stamp, no stream synchronise
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._alloc(64)
 
@@ -119,14 +119,14 @@ class _Staging:
         return [out[i * nb:(i + 1) * nb] for i in range(n)]
 
     def _launch(self, n):
-        # launch + hipStreamSynchronize in one call, on the caller's current stream (raw handle)
+        # launch + wait for the out records' stamps in one call, on the caller's current stream (raw handle)
         if torch.cuda.current_device() == self.device.index:
             rc = self.op_sync(self.p_in, self.p_out, n, _raw_stream(self.device.index))
         else:
             with torch.cuda.device(self.device):
                 rc = self.op_sync(self.p_in, self.p_out, n, _raw_stream(self.device.index))
         if rc:
-            _native.check(rc, "qttt_board_op_sync")
+            _native.check(rc, "qttt_board_op_host")
 
 
 _PAD18 = b"\xff" * 18

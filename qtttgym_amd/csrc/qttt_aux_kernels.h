@@ -447,7 +447,9 @@ __global__ __launch_bounds__(BLOCK) void import_kernel(u64 *pP, u64 *pQ, ExpOut 
 // batch kernels run -> export + check_win, in one launch, so that the single-board façade costs one
 // round trip.  The records may live in pinned host memory (the kernel reads and writes them
 // directly).
-__global__ __launch_bounds__(QTTT_COLD_BLOCK) void board_op_kernel(const uint8_t *in, uint8_t *out, int64_t n) {
+// stamp != 0: the record's last byte receives it after everything else of the record is visible system-wide, so a host
+// that owns the (pinned) records can poll for completion instead of synchronising the stream (qttt_board_op_host).
+__global__ __launch_bounds__(QTTT_COLD_BLOCK) void board_op_kernel(const uint8_t *in, uint8_t *out, int64_t n, u32 stamp) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     fill_line_lut<QTTT_COLD_BLOCK>(lut);
     int64_t i = (int64_t)blockIdx.x * QTTT_COLD_BLOCK + threadIdx.x;
@@ -504,6 +506,10 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void board_op_kernel(const uint8_t
     o[49] = (uint8_t)(int8_t)p1;
     o[50] = (uint8_t)(int8_t)p2;
     (void)win;
+    if (stamp) {
+        __threadfence_system();
+        *reinterpret_cast<volatile uint8_t *>(o + QTTT_BOARD_RECORD_BYTES - 1) = (uint8_t)stamp;
+    }
 }
 
 // legal pairs in ind2move order: for lo ascending, hi ascending (mcts.py:20-27, 339-343).  Two boards

@@ -48,6 +48,7 @@
 // qttt_observation.h -> qttt_step_kernels.h; qttt_board_forms.h (unpacked views, winner, legal mask,
 // tuple hash) -> qttt_aux_kernels.h, qttt_mcts_kernels.h; this file: launch logic + the C ABI.
 #include <atomic>
+#include <chrono>
 #include "qttt_step_kernels.h"
 #include "qttt_aux_kernels.h"
 #include "qttt_mcts_kernels.h"
@@ -439,18 +440,53 @@ int qttt_import(void *state, const uint8_t *moves, const uint8_t *n_moves, const
     return launch_status();
 }
 
-int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *stream) {
+static int launch_board_op(const void *records_in, void *records_out, int64_t n, void *stream, u32 stamp) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!records_in || !records_out) return QTTT_ERR_NULL;
     hipLaunchKernelGGL(board_op_kernel, dim3(cold_grid_for(n)), dim3(QTTT_COLD_BLOCK), 0, (hipStream_t)stream,
-                       (const uint8_t *)records_in, (uint8_t *)records_out, n);
+                       (const uint8_t *)records_in, (uint8_t *)records_out, n, stamp);
     return launch_status();
+}
+
+int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *stream) {
+    return launch_board_op(records_in, records_out, n, stream, 0u);
 }
 
 int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, void *stream) {
     const int rc = qttt_board_op(records_in, records_out, n, stream);
     if (rc) return rc;
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// Records in HOST-accessible pinned memory: the host clears the stamp byte of every out record, launches, and polls the
+// stamps — the kernel writes a record's stamp after the record itself is visible system-wide.  tools/sync_latency, one
+// record: launch + hipStreamSynchronize 14.7 - 16.0 us per call, launch + poll 9.7.  A poll that has not ended after
+// ~2 ms (or a batch too large to poll) falls back to synchronising the stream, so the call always returns.
+int qttt_board_op_host(const void *records_in, void *records_out, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!records_in || !records_out) return QTTT_ERR_NULL;
+    constexpr int64_t POLL_MAX_RECORDS = 256;
+    volatile uint8_t *out = static_cast<volatile uint8_t *>(records_out);
+    const bool poll = n <= POLL_MAX_RECORDS;
+    if (poll)
+        for (int64_t i = 0; i < n; ++i) out[i * QTTT_BOARD_RECORD_BYTES + QTTT_BOARD_RECORD_BYTES - 1] = 0;
+    std::atomic_thread_fence(std::memory_order_release);
+    const int rc = launch_board_op(records_in, records_out, n, stream, poll ? 1u : 0u);
+    if (rc) return rc;
+    if (poll) {
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        bool done = false;
+        for (unsigned spin = 1; !done; ++spin) {
+            done = true;
+            for (int64_t i = n - 1; i >= 0 && done; --i) done = out[i * QTTT_BOARD_RECORD_BYTES + QTTT_BOARD_RECORD_BYTES - 1] != 0;
+            if (!done && (spin & 1023u) == 0u && std::chrono::steady_clock::now() > give_up) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (done) return 0;
+    }
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
 }

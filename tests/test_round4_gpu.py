@@ -321,3 +321,29 @@ def test_board_attributes_are_mutated_in_place():
     c = Board(Fixed())
     cm, cq = c.moves, c.qstructs
     assert Board.make_moves([c], [(4, 8)]) == [None] and c.moves is cm and cm == [(4, 8, 0)] and c.qstructs is cq
+
+
+def test_board_op_host_polls_the_stamp_and_equals_board_op_sync():
+    """qttt_board_op_host (records in pinned host memory, completion by polling byte 63 of the out records) gives the
+    records qttt_board_op_sync gives, for one record, a node's 36 actions, and a batch beyond the polling limit."""
+    from qtttgym_amd import Board, QEvalClassic, _native
+    from qtttgym_amd.board import _Staging
+    L = _native.lib()
+    parent = Board(QEvalClassic())
+    for mv in ((0, 1), (1, 2), (3, 4), (2, 3), (5, 6)):
+        parent.make_move(mv)
+    pairs = [(i, j) for i in range(9) for j in range(i + 1, 9)]
+    s = torch.cuda.current_stream().cuda_stream
+    for n in (1, 36, 300):
+        recs = [_Staging.pack(parent, _native.OP_MAKE_MOVE, *pairs[k % 36], k & 1) for k in range(n)]
+        t_in = torch.zeros(64 * n, dtype=torch.uint8).pin_memory()
+        t_in.numpy()[:] = np.frombuffer(b"".join(r + bytes(23) for r in recs), dtype=np.uint8)
+        a = torch.full((64 * n,), 7, dtype=torch.uint8).pin_memory()
+        b = torch.full((64 * n,), 9, dtype=torch.uint8).pin_memory()
+        assert L.qttt_board_op_sync(t_in.data_ptr(), a.data_ptr(), n, s) == 0
+        assert L.qttt_board_op_host(t_in.data_ptr(), b.data_ptr(), n, s) == 0
+        ra, rb = a.numpy().reshape(n, 64), b.numpy().reshape(n, 64)
+        assert np.array_equal(ra[:, :42], rb[:, :42]) and np.array_equal(ra[:, 44:51], rb[:, 44:51])   # (bytes 42, 43 are padding)
+        assert (rb[:, 63] == (1 if n <= 256 else 9)).all()          # stamped when polled; untouched on the fallback path
+        assert (ra[:, 41] == 1).sum() > 0 and (ra[:, 41] == 0).sum() > 0 if n > 1 else True
+    assert L.qttt_board_op_host(None, None, 1, s) == -1 and L.qttt_board_op_host(None, None, 0, s) == 0

@@ -73,7 +73,7 @@ def main():
                       "expand_36_children_loop_of_make_move_us_per_child": t_loop * 1e6,
                       "expand_36_children_one_make_moves_call_us_per_child": t_batch * 1e6,
                       "Board.check_win_us": t_cw * 1e6, "reference_Env.step_us": 12.0,
-                      "note": "Env.step = one qttt_board_op launch + one stream synchronise (check_win comes back in the same record); the loop also pays the random legal move and Env.reset of each episode"}))
+                      "note": "Env.step = one qttt_board_op_host call: a launch + polling the out record's stamp in pinned memory (check_win comes back in the same record); the loop also pays the random legal move and Env.reset of each episode"}))
 
 
 if __name__ == "__main__":
