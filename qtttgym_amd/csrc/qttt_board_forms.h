@@ -381,15 +381,6 @@ struct PyHashWalk {
     }
 };
 
-__device__ __forceinline__ int64_t fast_py_hash(const Lite &s, u32 P1_stored, u32 Q0, const u64 *tbl) {
-    PyHashWalk w;
-    w.init(s, P1_stored, Q0);
-#pragma unroll
-    for (u32 v = 0; v < 9; ++v) w.board_elem(v, s.cl, tbl);
-    for (u32 t = 0; t < w.n8; ++t) w.move_elem(t, tbl);
-    return w.finish(s.n, tbl);
-}
-
 // Two boards at once: the hash is a chain of dependent steps (add, rotate, 64-bit multiply, next table
 // address) and every step waits on a 64-bit LDS gather, so one chain per lane leaves the SIMD waiting
 // (~6.6 cycles per instruction at 8 waves per SIMD); two independent chains in one

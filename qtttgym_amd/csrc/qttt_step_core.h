@@ -187,13 +187,6 @@ __device__ __forceinline__ u32 step_core_both(u32 P0, u32 P1, u32 &Q0, u32 &Q1, 
     return s.legal ? (s.cyc ? 2u : 1u) : 0u;
 }
 
-// classical mask the policy sees (a finished board counts as empty under auto-reset)
-template <bool AUTO_RESET>
-__device__ __forceinline__ u32 policy_empty_mask(u32 P1) {
-    const u32 cl = (AUTO_RESET && (P1 >> 31)) ? 0u : (P1 >> P1_CL_SHIFT) & 0x1FFu;
-    return ~cl & 0x1FFu;
-}
-
 }  // namespace
 
 #endif  // QTTT_STEP_CORE_H
