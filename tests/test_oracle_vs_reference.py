@@ -93,3 +93,39 @@ def test_reference_draws_one_bit_per_collapse_only():
             env.step(tuple(rng.sample(empty, 2)))
             collapsed = before != env._gameboard.board
             assert src.calls - calls == (1 if collapsed else 0)
+
+
+def test_host_side_mirrors_against_the_reference_live(capsys):
+    """The pieces of the host mirror that are plain Python (no device work) against the imported reference:
+    `displayBoard` prints what display.py:4-32 prints for the same attributes, and `ind2move` / `move2ind`
+    (qtttgym_amd.actions) are mcts.py:339-350's tables."""
+    import sys
+    from ref_shim import REFERENCE_ROOT
+    qtttgym, src = load_reference()
+    from qtttgym_amd.board import displayBoard
+    from qtttgym_amd.actions import ind2move, move2ind
+    rng = random.Random(77)
+
+    class Attrs:                                  # the duck type both renderers read: .moves and .board
+        pass
+    for _ in range(200):
+        gb = qtttgym.Board(qtttgym.QEvalClassic())
+        for _ in range(rng.randrange(0, 10)):
+            empty = [i for i in range(9) if gb.board[i] == -1]
+            if len(empty) < 2:
+                break
+            src.bit = rng.getrandbits(1)
+            gb.make_move(tuple(rng.sample(empty, 2)))
+        qtttgym.displayBoard(gb)
+        want = capsys.readouterr().out
+        mine = Attrs()
+        mine.moves, mine.board = list(gb.moves), list(gb.board)
+        displayBoard(mine)
+        assert capsys.readouterr().out == want
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import mcts as ref_mcts
+    for a in range(36):
+        assert tuple(ind2move(a)) == tuple(ref_mcts.ind2move(a))
+        i, j = ref_mcts.ind2move(a)
+        assert move2ind(i, j) == ref_mcts.move2ind(i, j) == a and move2ind(j, i) == ref_mcts.move2ind(j, i)
