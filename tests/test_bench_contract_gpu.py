@@ -119,7 +119,7 @@ def test_bench_default_line_carries_the_legs():
     assert 1.0 < c5["children_per_pair"] < 1.6
     # the native position key costs a fraction of the CPython-exact one
     assert legs["row_node_info_1048576_boards"]["us_per_launch"] < 0.8 * legs["row_node_info_python_key_1048576_boards"]["us_per_launch"]
-    assert legs["row_expand_1048576_boards"]["us_per_launch"] < 0.8 * legs["row_expand_python_key_1048576_boards"]["us_per_launch"]
+    assert legs["row_expand_1048576_boards"]["us_per_launch"] < 0.85 * legs["row_expand_python_key_1048576_boards"]["us_per_launch"]
     # both roofline fractions in the line: against the spec and against the achievable copy rate, and the same
     # kernel beyond the Infinity Cache
     r = d["roofline"]
