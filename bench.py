@@ -140,17 +140,24 @@ def self_launch(args):
 def pmc_traffic_per_launch(boards, state_bytes, suffix=""):
     """HBM bytes per step launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction in
-    MI355X_MICROARCH.md §HBM).  Not measured in this run: `traffic_source` names the file.
-    None if no summary for this batch size / state layout is committed."""
+    MI355X_MICROARCH.md §HBM).  Not measured in this run (a process cannot read the PMC counters of its own
+    kernels without the profiler): `traffic_source` names the file, and the second value returned says whether the
+    passes were made on the step-kernel sources this run was built from (tools/pmc_summary.py's fingerprint).
+    (None, None) if no summary for this batch size / state layout is committed."""
     try:
         with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             d = json.load(f)
         e = d.get("%d@%dB%s" % (boards, state_bytes, suffix))
         if e is None or int(e.get("state_bytes_per_board", 20)) != state_bytes:
-            return None
-        return float(e["hbm_bytes_per_launch"])
+            return None, None
+        import hashlib
+        h = hashlib.sha256()
+        for name in ("qttt_state.h", "qttt_step_core.h", "qttt_observation.h", "qttt_step_kernels.h"):
+            with open(os.path.join(ROOT, "qtttgym_amd", "csrc", name), "rb") as src:
+                h.update(src.read())
+        return float(e["hbm_bytes_per_launch"]), e.get("step_sources_sha256") == h.hexdigest()[:16]
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def cpu_model():
@@ -659,8 +666,8 @@ def run(args):
             achieved = algo_bytes * B / launch_s / 1e9
             bpl, blk = wl.shape                                            # the library's own choice for this batch
             gym = args.mode == "gym"
-            traffic = (pmc_traffic_per_launch(B, state_bytes) if args.mode == "replay" else
-                       pmc_traffic_per_launch(B, state_bytes, "+gym") if gym else None)
+            traffic, traffic_fresh = (pmc_traffic_per_launch(B, state_bytes) if args.mode == "replay" else
+                                      pmc_traffic_per_launch(B, state_bytes, "+gym") if gym else (None, None))
             what = WHAT[args.mode] % args.fused_steps if args.mode == "random-fused" else WHAT[args.mode]
             out = {
                 "metric": "env_steps_per_sec", "value": value, "unit": "steps/s", "n_gpus": world,
@@ -683,6 +690,7 @@ def run(args):
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "traffic_source": None if traffic is None else PMC_SUMMARY,
+                             "traffic_measured_on_this_build": traffic_fresh,
                              "kernel": kernel_label(args.mode, bpl, blk), "launch_us": launch_s * 1e6,
                              "algorithmic_bytes_per_board_step": algo_bytes,
                              "algorithmic_bytes_per_launch": algo_bytes * B,

@@ -47,6 +47,8 @@ def test_bench_json_contract_small_batch():
     assert abs(r["launch_us"] - d["ms_per_step"] * 1e3) < 1e-9
     assert d["host_wall_ms_per_step"] >= d["ms_per_step"] * 0.98
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
+    # the committed PMC figure says whether it was collected on the step-kernel sources this run was built from
+    assert r["traffic_measured_on_this_build"] in (True, False, None) and (r["traffic"] is None) == (r["traffic_measured_on_this_build"] is None)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "steps/s" and c["cores"] >= 1 and c["value"] > 1e6
     assert c["python_interpreter_steps_per_s"] > 1e4

@@ -31,6 +31,19 @@ def mean_counter(d, name):
     return sum(vals) / len(vals), len(vals)
 
 
+STEP_SOURCES = ("qttt_state.h", "qttt_step_core.h", "qttt_observation.h", "qttt_step_kernels.h")
+
+
+def step_sources_sha256():
+    """Fingerprint of the sources the step kernels are made of: bench.py reports whether the committed traffic figure
+    was collected on the build it is running (`roofline.traffic_measured_on_this_build`)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in STEP_SOURCES:
+        h.update(open(os.path.join(ROOT, "qtttgym_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     boards, fetch_dir, write_dir = sys.argv[1], sys.argv[2], sys.argv[3]
     label = sys.argv[4] if len(sys.argv) > 4 else ""
@@ -46,6 +59,7 @@ def main():
         "dispatches": [nf, nw], "label": label, "state_bytes_per_board": state_bytes,
         "algorithmic_bytes_per_launch": (2 * state_bytes + 7 + extra) * int(boards),
         "note": "FETCH_SIZE doubled (gfx950 half-count of wide coalesced reads); separate --pmc passes",
+        "step_sources_sha256": step_sources_sha256(),
     }
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     d = json.load(open(path)) if os.path.exists(path) else {}
