@@ -4,9 +4,10 @@
  *
  * Conventions
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
- *     (contiguous; torch-ROCm tensors in the host package), nothing is allocated or freed here;
+ *     (contiguous; torch-ROCm tensors in the host package), nothing is allocated or freed here (the records of
+ *     qttt_board_op* only need to be device-ACCESSIBLE: pinned host memory works, and qttt_board_op_host requires it);
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and ordered by it;
- *     no call synchronises the device (qttt_board_op_sync, which says so, is the one exception);
+ *     no call waits for the device (qttt_board_op_sync and qttt_board_op_host, which say so, are the two exceptions);
  *   - return value: 0 = ok, >0 = hipError_t of the launch, <0 = argument error
  *     (QTTT_ERR_NULL / QTTT_ERR_SIZE / QTTT_ERR_ACTION = a pointer not aligned as the entry needs);
  *   - the library keeps no per-call and no per-environment state: every entry point may be called from

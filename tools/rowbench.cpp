@@ -109,6 +109,56 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused2_kernel(
     store_stream(&reinterpret_cast<V64 *>(pQ)[j], qo);
 }
 
+// Experiment: node_info (winner, terminal, legal mask, native key) with no LDS table and no workgroup barrier — the line
+// test and the legal mask done arithmetically (more VALU, but the kernel is traffic-bound and a wave then depends on
+// nothing but its own loads).  Same outputs as node_info_kernel<BLOCK, false>.
+__device__ __forceinline__ bool has_line_arith(u32 m) {
+    const u32 rows = m & (m >> 1) & (m >> 2) & 0x049u, cols = m & (m >> 3) & (m >> 6) & 0x007u;
+    return ((rows | cols) != 0u) | ((m & 0x111u) == 0x111u) | ((m & 0x054u) == 0x054u);
+}
+__device__ __forceinline__ void winner_arith(const Lite &s, int &winner, int &terminal) {
+    const u32 W = (u32)(s.P >> 2);
+    const u32 c8 = (u32)(s.P >> 34) & 0xFu;
+    const u32 par = W & 0x11111111u;
+    const u32 even = __builtin_amdgcn_udot8(par, 0x00008421u, 0u, false) |
+                     (__builtin_amdgcn_udot8(par, 0x84210000u, 0u, false) << 4) | ((c8 & 1u) << 8);
+    const u32 X = s.cl & even, O = s.cl & ~even;
+    const bool hx = has_line_arith(X), ho = has_line_arith(O);
+    winner = hx ? 1 : (ho ? 0 : -1);
+    if (hx && ho) {
+        u32 ge[3];
+#pragma unroll
+        for (u32 k = 0; k < 3; ++k) {
+            const u32 T = 9u + k;
+            const u32 y = ((W & 0x77777777u) + 0x11111111u * (16u - T)) & W & 0x88888888u;
+            ge[k] = ((__builtin_amdgcn_udot8(y, 0x00008421u, 0u, false) |
+                      (__builtin_amdgcn_udot8(y, 0x84210000u, 0u, false) << 4)) >> 3) | ((c8 >= T ? 1u : 0u) << 8);
+        }
+        winner = (has_line_arith(X & ge[2]) || (has_line_arith(X & ge[0]) && !has_line_arith(O & ge[1]))) ? 1 : 0;
+    }
+    terminal = (s.n == 9u || hx || ho) ? 1 : 0;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void node_info_nolds_kernel(const u64 *pP, const u64 *pQ, int8_t *winner, uint8_t *terminal,
+                                                                u64 *legal, u64 *skey, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t i0 = 2 * j;
+    if (i0 + 1 >= n) return;                                            // (experiment: even batches only)
+    typedef Vec<u64, 2> V64;
+    const V64 p = load_stream(&reinterpret_cast<const V64 *>(pP)[j]), q = load_stream(&reinterpret_cast<const V64 *>(pQ)[j]);
+    V64 k2, l2;
+    k2.v[0] = state_key(p.v[0], (u32)q.v[0]); k2.v[1] = state_key(p.v[1], (u32)q.v[1]);
+    store_stream(&reinterpret_cast<V64 *>(skey)[j], k2);
+    const Lite sa = lite_unpack(p.v[0]), sb = lite_unpack(p.v[1]);
+    int wa, ta, wb, tb;
+    winner_arith(sa, wa, ta);
+    winner_arith(sb, wb, tb);
+    reinterpret_cast<uint16_t *>(winner)[j] = (uint16_t)((u32)(wa & 0xFF) | ((u32)(wb & 0xFF) << 8));
+    reinterpret_cast<uint16_t *>(terminal)[j] = (uint16_t)((u32)ta | ((u32)tb << 8));
+    l2.v[0] = fast_legal_mask(sa.cl); l2.v[1] = fast_legal_mask(sb.cl);
+    store_stream(&reinterpret_cast<V64 *>(legal)[j], l2);
+}
+
 struct Variant {
     std::string name;
     std::function<void(hipStream_t)> launch;
@@ -156,6 +206,11 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL((node_info_kernel<BLK, false>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,  \
                            p.P, p.Q, (int8_t *)nullptr, (uint8_t *)nullptr, (u64 *)nullptr, (int64_t *)nullptr, skey, n); }, {}});
     NIV(256) NIV(512) NIV(1024)
+#define NIA(BLK)                                                                                                         \
+    vs.push_back({"node_info_nolds<" #BLK "> native key, arithmetic line test + legal mask (experiment)", [=](hipStream_t st) { \
+        hipLaunchKernelGGL((node_info_nolds_kernel<BLK>), dim3((unsigned)(((n + 1) / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st,  \
+                           p.P, p.Q, winner, terminal, legal, skey, n); }, {}});
+    NIA(256) NIA(512) NIA(1024)
     uint8_t *act36, *nch; u64 *kid0, *kid1; int8_t *w2; uint8_t *t2; u64 *l2; int64_t *k2; u64 *sk2; int32_t *vsum;
     CK(hipMalloc(&act36, n));
     { std::vector<uint8_t> ha(n); u32 x = 12345u; for (auto &v : ha) { x = x * 1664525u + 1013904223u; v = (uint8_t)((x >> 16) % 36u); }
