@@ -1,0 +1,33 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import torch
+from qtttgym_amd import VecEnv
+dev = torch.device("cuda", 0)
+for B in (1 << 20, 262144, 4096):
+    K, W = 20, 5
+    env = VecEnv(B, device=dev, seed=1, auto_reset=True)
+    T = K + W
+    actions = torch.empty((T, B, 2), dtype=torch.uint8, device=dev)
+    for t in range(T):
+        env.sample_actions(out=actions[t]); env.step_raw(actions[t])
+    torch.cuda.synchronize()
+    final = env.state.clone()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def preroll():
+        env.reset_raw(); env.step_many(actions[:W])
+    # eager
+    def region_eager():
+        preroll(); e0.record(); env.step_many(actions[W:]); e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) * 1e3 / K
+    # graph of the K timed launches
+    preroll(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(); side = torch.cuda.Stream(device=dev); side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            env.step_many(actions[W:])
+    torch.cuda.current_stream(dev).wait_stream(side); torch.cuda.synchronize()
+    def region_graph():
+        preroll(); e0.record(); g.replay(); e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) * 1e3 / K
+    for name, fn in (("eager", region_eager), ("graph", region_graph), ("eager", region_eager), ("graph", region_graph)):
+        us = sorted(fn() for _ in range(300))
+        ok = torch.equal(env.state, final)
+        print(B, name, "median %.3f us  min %.3f  replay_ok %s" % (us[len(us)//2], us[0], ok), flush=True)
