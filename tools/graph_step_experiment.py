@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Experiment (not the judged bench): the K = 20 timed step launches of bench.py's replay region enqueued eagerly from C
+(qttt_step_many) against the same launches captured once in a hipGraph and replayed, per batch size.  Round 4, one
+MI355X (profiles/r04/graph_vs_eager_step.txt): 1 M boards 7.15 - 7.21 us eager / 7.50 - 7.84 graph (a replay's own cost
+does not amortise over 20 launches of 7 us), 262 144 boards 3.85 - 3.92 / 3.90 - 3.91, 4 096 boards 3.58 - 3.78 / 2.65.
+So the headline stays on the eager C loop; graphs pay for small batches only (VecEnv.capture)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
