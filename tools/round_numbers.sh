@@ -3,7 +3,7 @@
 # (un-profiled; the rocprofv3 passes are tools/profile_round.sh).  The stepbench A/B line wants one extra build under
 # gpurun_tmp/ (git-ignored, travels with gpurun):
 #   gpurun_tmp/libstamp/libqttt_hip.so  this tree with -DQTTT_DEBUG_STAMPS (per-wave timeline):
-#       hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=16 -DQTTT_DEBUG_STAMPS -Iinclude -o gpurun_tmp/libstamp/libqttt_hip.so qtttgym_amd/csrc/qttt_kernels.hip
+#       hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=4 -DQTTT_DEBUG_STAMPS -Iinclude -o gpurun_tmp/libstamp/libqttt_hip.so qtttgym_amd/csrc/qttt_kernels.hip
 set -u
 out=$1; mkdir -p "$out"
 b() { name=$1; shift; python3 bench.py "$@" > "$out/$name.json" 2> "$out/$name.err"; echo "$name rc=$? $(cut -c1-120 "$out/$name.json")"; }
