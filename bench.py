@@ -503,9 +503,10 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
 # SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 155 497 902 per dispatch of 1 048 576 boards x
 # 64 steps = 9 490.8 per wave = 148.3 per ply (profiles/r04/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass)
 FUSED_VALU_PER_STEP = 148.3
-# issue time of that instruction mix per wave and ply (tools/isa_mix.py: 65 % of the 147.3 in the slow class, 1.75 ns
-# per instruction per SIMD, the rest at 1.03 ns): what a SIMD needs per resident wave and ply when it never idles
-FUSED_ISSUE_NS_PER_WAVE_PLY = 220.8
+# issue time of that instruction mix per wave and ply (tools/isa_mix.py: 57 % of the 148.3 in the slow class, 1.75 ns
+# per instruction per SIMD, the rest at 1.03 ns — a literal operand does not make a logic instruction slow, an SGPR
+# operand does: profiles/r02/valu_rates.txt): what a SIMD needs per resident wave and ply when it never idles
+FUSED_ISSUE_NS_PER_WAVE_PLY = 213.7
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):

@@ -50,7 +50,9 @@ def main():
             continue
         op, enc, args = m.group(1), m.group(2) or "", m.group(3)
         rest = args.split(",", 1)[1] if "," in args else ""
-        scalar_operand = bool(re.search(r"\bs\d|s\[\d|0x[0-9a-f]{3,}|\bvcc\b", rest.split(" bitop3")[0]))
+        # an SGPR (or vcc) source puts a plain-logic instruction in the slow class (valu_rates: k_and_s, k_bitop3_s, k_mov_s
+        # x1.7); a 32-bit LITERAL does not (k_and_lit, k_bitop3_c x0.92 - 0.95) — round 3 counted literals as slow
+        scalar_operand = bool(re.search(r"\bs\d|s\[\d|\bvcc\b", rest.split(" bitop3")[0]))
         is_fast = op in FAST and enc != "_sdwa" and not scalar_operand
         if in_walk:
             walk_fast += is_fast
