@@ -348,3 +348,61 @@ def test_board_op_host_polls_the_stamp_and_equals_board_op_sync():
         if n > 1:                                                       # both kinds of answers are in the batch
             assert (ra[:, 41] == 1).sum() > 0 and (ra[:, 41] == 0).sum() > 0
     assert L.qttt_board_op_host(None, None, 1, s) == -1 and L.qttt_board_op_host(None, None, 0, s) == 0
+
+
+# ---------------------------------------------------------------------------------------- exhaustive: every position to depth 4
+def _cat_states(parts, seed=0):
+    """One VecEnv over the boards of several (VecEnv, index tensor) selections (plane indexing, nothing unpacked)."""
+    from qtttgym_amd import VecEnv, _native
+    cols = [e.state.view(torch.int64).view(2, -1)[:, idx] for e, idx in parts]
+    planes = torch.cat(cols, dim=1)
+    m = planes.shape[1]
+    st = torch.zeros(int(_native.lib().qttt_state_bytes(m)), dtype=torch.uint8, device=planes.device)
+    st.view(torch.int64).view(2, -1)[:, :m] = planes
+    return VecEnv.from_state(st, m, seed=seed)
+
+
+def test_every_position_reachable_in_four_plies_has_its_own_key_and_survives_export_import():
+    """Exhaustive, not sampled: all positions reachable from the empty board in <= 4 plies — every legal action, both
+    branches of every collapse; (board, moves) holds the move ORDER, so every path is a position of its own — are
+    generated with qttt_expand.  At every depth: as many distinct native keys as positions (no collision at all among
+    ~1.7 M positions), the same for CPython's hash, import(export(s)) == s bit for bit, and at depths <= 2 the set of
+    positions is the one the oracle's expand enumerates."""
+    from qtttgym_amd import VecEnv
+    frontier = VecEnv(1)
+    total, all_nat = 1, [frontier.state_keys()]
+    ob_frontier = oracle.OracleBoards(1)
+    for depth in range(1, 5):
+        n = frontier.num_envs
+        rep = frontier.take(torch.arange(n, device="cuda").repeat_interleave(36))
+        act = torch.arange(36, dtype=torch.uint8, device="cuda").repeat(n)
+        out = rep.expand(act, python_key=True)
+        nch = out["n_children"]
+        i0, i1 = (nch >= 1).nonzero().flatten(), (nch == 2).nonzero().flatten()
+        nxt = _cat_states([(out["child0"], i0), (out["child1"], i1)])
+        m = nxt.num_envs
+        py = torch.cat([out["key"][i0, 0], out["key"][i1, 1]])
+        nat = torch.cat([out["state_key"][i0, 0], out["state_key"][i1, 1]])
+        assert torch.unique(py).numel() == m and torch.unique(nat).numel() == m, (depth, m)
+        info = nxt.node_info()
+        assert torch.equal(info["key"], py) and torch.equal(info["state_key"], nat)
+        ex = nxt.export_boards()
+        back = VecEnv(m)
+        back.import_boards(ex["moves"], ex["n_moves"], ex["board"], ex["qmask"], ex["n_q"])
+        assert torch.equal(back.state.view(torch.int64).view(2, -1)[:, :m], nxt.state.view(torch.int64).view(2, -1)[:, :m]), depth
+        if depth <= 2:                                   # the same set of positions as the oracle's MCTS._step restatement
+            pn = ob_frontier.n
+            ob_rep = oracle.OracleBoards(pn * 36)
+            ob_rep.b[:] = np.repeat(ob_frontier.b, 36)
+            o_nch, kids, _, _, _, o_key = oracle.expand(ob_rep, np.tile(np.arange(36, dtype=np.uint8), pn))
+            assert np.array_equal(_np(nch), o_nch)
+            o_py = np.concatenate([o_key[o_nch >= 1, 0], o_key[o_nch == 2, 1]])
+            assert np.array_equal(np.sort(_np(py)), np.sort(o_py))
+            ob_frontier = oracle.OracleBoards(m)
+            ob_frontier.b[:] = np.concatenate([kids[0].b[o_nch >= 1], kids[1].b[o_nch == 2]])
+        all_nat.append(nat)
+        total += m
+        frontier = nxt
+    # 36 first moves; a second move on the same pair closes a 2-cycle (two children), any other does not: 36 * 37
+    assert [int(x.numel()) for x in all_nat[:3]] == [1, 36, 36 * 35 + 36 * 2]
+    assert total > 1_500_000 and torch.unique(torch.cat(all_nat)).numel() == total      # no collision across depths either
