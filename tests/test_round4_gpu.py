@@ -362,24 +362,65 @@ def _cat_states(parts, seed=0):
     return VecEnv.from_state(st, m, seed=seed)
 
 
+def _next_level(frontier):
+    """All children of all 36 actions of every board of `frontier` (both branches of a collapse): (VecEnv, expand output,
+    index of the rows with a first child, index of those with a second)."""
+    n = frontier.num_envs
+    rep = frontier.take(torch.arange(n, device="cuda").repeat_interleave(36))
+    act = torch.arange(36, dtype=torch.uint8, device="cuda").repeat(n)
+    out = rep.expand(act, python_key=True)
+    nch = out["n_children"]
+    i0, i1 = (nch >= 1).nonzero().flatten(), (nch == 2).nonzero().flatten()
+    return _cat_states([(out["child0"], i0), (out["child1"], i1)]), out, i0, i1
+
+
+def test_every_transition_from_every_position_to_depth_three_vs_oracle():
+    """Exhaustive step parity: from EVERY position reachable in <= 3 plies (~48 000), every action of {0..9}^2 plus two
+    with a square of 255 (same-square, classical-square and out-of-range noops included), with the collapse bit 0 and
+    1 — 9.9 M transitions — through qttt_step against the oracle's Env.step: state, reward bits, terminated."""
+    from qtttgym_amd import VecEnv
+    depth = int(os.environ.get("QTTT_EXHAUSTIVE_DEPTH", "3"))        # 4: ~1.7 M positions, 3.5e8 transitions, minutes (a one-off:
+    levels = [VecEnv(1)]                                             # profiles/r04/exhaustive_transitions_depth4.txt)
+    for _ in range(depth):
+        levels.append(_next_level(levels[-1])[0])
+    pos = _cat_states([(e, torch.arange(e.num_envs, device="cuda")) for e in levels])
+    n = pos.num_envs
+    assert n == 1 + 36 + 36 * 37 + sum(e.num_envs for e in levels[3:]) and n > 45000
+    print("exhaustive transitions: %d positions to depth %d x %d actions x 2 bits" % (n, depth, 102))
+    ex = {k: _np(v) for k, v in pos.export_boards().items()}
+    ob0 = oracle.boards_from_arrays(ex["board"], ex["moves"], ex["n_moves"], ex["qmask"].view(np.uint16), ex["n_q"])
+    actions = [(a, b) for a in range(10) for b in range(10)] + [(255, 0), (3, 255)]
+    start = pos.state.clone()
+    for a, b in actions:
+        act = torch.tensor([a, b], dtype=torch.uint8, device="cuda").repeat(n, 1).contiguous()
+        act_np = np.tile(np.array([a, b], dtype=np.uint8), (n, 1))
+        for bit in (0, 1):
+            pos.state.copy_(start)
+            bits = torch.full((n,), bit, dtype=torch.uint8, device="cuda")
+            reward, term = pos.step_raw(act, bits)
+            ob = ob0.copy()
+            r_o, t_o = ob.step(act_np, np.full(n, bit, dtype=np.uint8))
+            assert np.array_equal(_np(reward).view(np.uint32), r_o.view(np.uint32)), (a, b, bit)
+            assert np.array_equal(_np(term).astype(np.uint8), t_o), (a, b, bit)
+            e2 = {k: _np(v) for k, v in pos.export_boards().items()}
+            assert np.array_equal(e2["board"], ob.board) and np.array_equal(e2["moves"], ob.moves), (a, b, bit)
+            assert np.array_equal(e2["n_moves"], ob.n_moves) and np.array_equal(e2["n_q"], ob.n_q), (a, b, bit)
+            assert np.array_equal(e2["qmask"].view(np.uint16), ob.qmask), (a, b, bit)
+
+
 def test_every_position_reachable_in_four_plies_has_its_own_key_and_survives_export_import():
     """Exhaustive, not sampled: all positions reachable from the empty board in <= 4 plies — every legal action, both
     branches of every collapse; (board, moves) holds the move ORDER, so every path is a position of its own — are
     generated with qttt_expand.  At every depth: as many distinct native keys as positions (no collision at all among
-    ~1.7 M positions), the same for CPython's hash, import(export(s)) == s bit for bit, and at depths <= 2 the set of
+    ~1.7 M positions), the same for CPython's hash, import(export(s)) == s bit for bit, and at depths <= 3 the set of
     positions is the one the oracle's expand enumerates."""
     from qtttgym_amd import VecEnv
     frontier = VecEnv(1)
     total, all_nat = 1, [frontier.state_keys()]
     ob_frontier = oracle.OracleBoards(1)
     for depth in range(1, 5):
-        n = frontier.num_envs
-        rep = frontier.take(torch.arange(n, device="cuda").repeat_interleave(36))
-        act = torch.arange(36, dtype=torch.uint8, device="cuda").repeat(n)
-        out = rep.expand(act, python_key=True)
+        nxt, out, i0, i1 = _next_level(frontier)
         nch = out["n_children"]
-        i0, i1 = (nch >= 1).nonzero().flatten(), (nch == 2).nonzero().flatten()
-        nxt = _cat_states([(out["child0"], i0), (out["child1"], i1)])
         m = nxt.num_envs
         py = torch.cat([out["key"][i0, 0], out["key"][i1, 1]])
         nat = torch.cat([out["state_key"][i0, 0], out["state_key"][i1, 1]])
@@ -390,7 +431,7 @@ def test_every_position_reachable_in_four_plies_has_its_own_key_and_survives_exp
         back = VecEnv(m)
         back.import_boards(ex["moves"], ex["n_moves"], ex["board"], ex["qmask"], ex["n_q"])
         assert torch.equal(back.state.view(torch.int64).view(2, -1)[:, :m], nxt.state.view(torch.int64).view(2, -1)[:, :m]), depth
-        if depth <= 2:                                   # the same set of positions as the oracle's MCTS._step restatement
+        if depth <= 3:                                   # the same set of positions as the oracle's MCTS._step restatement
             pn = ob_frontier.n
             ob_rep = oracle.OracleBoards(pn * 36)
             ob_rep.b[:] = np.repeat(ob_frontier.b, 36)
