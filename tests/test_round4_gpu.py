@@ -379,7 +379,7 @@ def test_every_transition_from_every_position_to_depth_three_vs_oracle():
     with a square of 255 (same-square, classical-square and out-of-range noops included), with the collapse bit 0 and
     1 — 9.9 M transitions — through qttt_step against the oracle's Env.step: state, reward bits, terminated."""
     from qtttgym_amd import VecEnv
-    depth = int(os.environ.get("QTTT_EXHAUSTIVE_DEPTH", "3"))        # 4: ~1.7 M positions, 3.5e8 transitions, minutes (a one-off:
+    depth = int(os.environ.get("QTTT_EXHAUSTIVE_DEPTH", "3"))        # 4: 1.9 M positions, 3.9e8 transitions, ~50 s (a one-off:
     levels = [VecEnv(1)]                                             # profiles/r04/exhaustive_transitions_depth4.txt)
     for _ in range(depth):
         levels.append(_next_level(levels[-1])[0])
@@ -412,7 +412,7 @@ def test_every_position_reachable_in_four_plies_has_its_own_key_and_survives_exp
     """Exhaustive, not sampled: all positions reachable from the empty board in <= 4 plies — every legal action, both
     branches of every collapse; (board, moves) holds the move ORDER, so every path is a position of its own — are
     generated with qttt_expand.  At every depth: as many distinct native keys as positions (no collision at all among
-    ~1.7 M positions), the same for CPython's hash, import(export(s)) == s bit for bit, and at depths <= 3 the set of
+    ~1.9 M positions), the same for CPython's hash, import(export(s)) == s bit for bit, and at depths <= 3 the set of
     positions is the one the oracle's expand enumerates."""
     from qtttgym_amd import VecEnv
     frontier = VecEnv(1)
