@@ -129,3 +129,73 @@ def test_host_side_mirrors_against_the_reference_live(capsys):
         assert tuple(ind2move(a)) == tuple(ref_mcts.ind2move(a))
         i, j = ref_mcts.ind2move(a)
         assert move2ind(i, j) == ref_mcts.move2ind(i, j) == a and move2ind(j, i) == ref_mcts.move2ind(j, i)
+
+
+def test_oracle_expand_equals_the_reference_step_exhaustively_to_depth_three():
+    """Exhaustive link of the pin chain on the reference's side: from the empty board, every action at every position to
+    depth 2 is run through the reference's own MCTS._step (unmodified mcts.py) — (1 + 36 + 1 332) x 36 = 49 284 calls —
+    and through the oracle's qo_expand; the children (both collapse branches), their winner / terminal / legal
+    actions and Python hash are the same, position by position.  (tests/test_round4_gpu.py then holds the HIP side
+    against the oracle over every position to depth 4.)"""
+    import sys
+    from ref_shim import REFERENCE_ROOT
+    qtttgym, _ = load_reference()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import mcts as ref_mcts
+
+    class Toggle:                                         # _step re-runs make_move until the other branch shows up
+        def __init__(self):
+            self.bit = 0
+
+        def choice(self, seq):
+            out = seq[self.bit]
+            self.bit ^= 1
+            return out
+    tog = Toggle()
+    saved = qtttgym.qeval.random
+    qtttgym.qeval.random = tog
+    try:
+        strat = ref_mcts.MCTS(rollouts=1, num_simulations=1)
+        GS = ref_mcts.MCTS.GameState
+        frontier = [GS([-1] * 9, [], True, None, False)]
+        ob_frontier = oracle.OracleBoards(1)
+        wcode = {True: 1, False: 0, None: -1}
+        calls = 0
+        for depth in range(3):
+            n = len(frontier)
+            ob_rep = oracle.OracleBoards(n * 36)
+            ob_rep.b[:] = np.repeat(ob_frontier.b, 36)
+            nch, kids, winner, terminal, legal, key = oracle.expand(ob_rep, np.tile(np.arange(36, dtype=np.uint8), n))
+            nxt, order = [], []
+            for i, gs in enumerate(frontier):
+                for a in range(36):
+                    lo, hi = ref_mcts.ind2move(a)
+                    tog.bit = 0
+                    try:
+                        ch = strat._step(gs, a)
+                    except Exception:
+                        ch = []
+                    calls += 1
+                    row = i * 36 + a
+                    assert len(ch) == nch[row], (depth, i, a)
+                    if len(ch) == 2:
+                        r = len(gs.moves)
+                        ch.sort(key=lambda k: 0 if k.board[lo] == r else 1)
+                    for c, k in enumerate(ch):
+                        assert list(kids[c].board[row]) == list(k.board)
+                        assert [tuple(m[:2]) for m in k.moves] == [tuple(int(x) for x in kids[c].b["moves"][row][j])
+                                                                   for j in range(len(k.moves))]
+                        assert wcode[k.winner] == winner[row, c] and bool(k.terminal) == bool(terminal[row, c])
+                        assert hash(k) == key[row, c]
+                        assert sum(1 << x for x in k.actions) == int(legal[row, c])
+                        nxt.append(k)
+                        order.append((c, row))
+            # the oracle's frontier in the same (generation) order as `nxt`
+            ob_next = oracle.OracleBoards(len(nxt))
+            for j, (c, row) in enumerate(order):
+                ob_next.b[j] = kids[c].b[row]
+            frontier, ob_frontier = nxt, ob_next
+        assert calls == 1 * 36 + 36 * 36 + 1332 * 36 and len(frontier) == 49896
+    finally:
+        qtttgym.qeval.random = saved
