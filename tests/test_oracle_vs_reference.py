@@ -199,3 +199,64 @@ def test_oracle_expand_equals_the_reference_step_exhaustively_to_depth_three():
         assert calls == 1 * 36 + 36 * 36 + 1332 * 36 and len(frontier) == 49896
     finally:
         qtttgym.qeval.random = saved
+
+
+def test_oracle_step_equals_the_reference_env_step_exhaustively_to_depth_two():
+    """Every position reachable in <= 2 plies (1 + 36 + 1 332) x every action of {0..9}^2 plus two with a square of 255 x
+    both collapse bits = 279 276 calls of the reference's own Env.step (same-square, classical-square and IndexError
+    noops included) against qo_step: board, moves, qstructs, reward bits (-0.0 / -1.0), terminated, check_win."""
+    import copy
+    qtttgym, src = load_reference()
+    positions = []
+
+    def grow(gb, depth):
+        positions.append(gb)
+        if depth == 2:
+            return
+        for a in range(9):
+            for b in range(a + 1, 9):
+                if gb.board[a] != -1 or gb.board[b] != -1:
+                    continue
+                for bit in (0, 1):
+                    src.bit = bit
+                    calls = src.calls
+                    k = copy.deepcopy(gb)
+                    k.make_move((a, b))
+                    if src.calls == calls and bit == 1:
+                        continue                          # no collapse: the bit was not consumed, one child only
+                    grow(k, depth + 1)
+    grow(qtttgym.Board(qtttgym.QEvalClassic()), 0)
+    assert len(positions) == 1 + 36 + 1332
+    n = len(positions)
+    mv = np.full((n, 9, 2), 255, dtype=np.uint8)
+    bd = np.zeros((n, 9), dtype=np.int8)
+    qm = np.zeros((n, 4), dtype=np.uint16)
+    nm = np.zeros(n, dtype=np.uint8)
+    nq = np.zeros(n, dtype=np.uint8)
+    for i, gb in enumerate(positions):
+        for t, m in enumerate(gb.moves):
+            mv[i, t] = m[:2]
+        bd[i], nm[i], nq[i] = gb.board, len(gb.moves), len(gb.qstructs)
+        for k, s in enumerate(gb.qstructs):
+            qm[i, k] = sum(1 << x for x in s)
+    ob0 = oracle.boards_from_arrays(bd, mv, nm, qm, nq)
+    actions = [(a, b) for a in range(10) for b in range(10)] + [(255, 0), (3, 255)]
+    env = qtttgym.Env()
+    for a, b in actions:
+        for bit in (0, 1):
+            ob = ob0.copy()
+            r_o, t_o = ob.step(np.tile(np.array([a, b], dtype=np.uint8), (n, 1)), np.full(n, bit, dtype=np.uint8))
+            p1_o, p2_o = ob.check_win()
+            for i, gb in enumerate(positions):
+                g = qtttgym.Board(gb.qeval)                # (a hand copy: deepcopy is most of this test's time)
+                g.board, g.moves, g.qstructs = list(gb.board), list(gb.moves), [set(q) for q in gb.qstructs]
+                env._gameboard = g
+                src.bit = bit
+                _, r, term, trunc, _ = env.step((a, b))
+                g = env._gameboard
+                assert list(ob.board[i]) == list(g.board), (a, b, bit, i)
+                assert int(ob.n_moves[i]) == len(g.moves), (a, b, bit, i)
+                assert [tuple(int(x) for x in ob.b["moves"][i][j]) for j in range(len(g.moves))] == [tuple(m[:2]) for m in g.moves]
+                assert [int(x) for x in ob.qmask[i][:len(g.qstructs)]] == [sum(1 << x for x in s) for s in g.qstructs], (a, b, bit, i)
+                assert np.float32(r).view(np.uint32) == r_o[i].view(np.uint32) and bool(term) == bool(t_o[i]) and trunc is False
+                assert g.check_win() == (int(p1_o[i]), int(p2_o[i]))
