@@ -447,3 +447,16 @@ def test_every_position_reachable_in_four_plies_has_its_own_key_and_survives_exp
     # 36 first moves; a second move on the same pair closes a 2-cycle (two children), any other does not: 36 * 37
     assert [int(x.numel()) for x in all_nat[:3]] == [1, 36, 36 * 35 + 36 * 2]
     assert total > 1_500_000 and torch.unique(torch.cat(all_nat)).numel() == total      # no collision across depths either
+
+
+def test_root_ucb_search_on_expand_rollout_beats_random():
+    """The operator composes into a search loop with torch ops only (select -> one launch -> update): a root-level PUCT
+    bandit (mcts.py:281-285) over qttt_expand_rollout wins clearly more often as P1 than a random P1 does (52.8 % + its
+    share of the double-line games); measured 93.5 % (2 048 games, 72 iterations x 4 playouts per child)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ucb_selfplay.py"), "--games", "512", "--iters", "48",
+                          "--sims", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    pct = float(out.stdout.split("(")[2].split("%")[0])
+    assert pct > 86.0, out.stdout
