@@ -372,8 +372,8 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
                           ((u64)((u32)(qm >> 32) & 0x1FFu) << 18) | ((u64)((u32)(qm >> 48) & 0x1FFu) << 27);
     const u64 comps = nqc >= 4u ? comps_all : comps_all & ((1ull << (9u * nqc)) - 1ull);
     // ---- the rooted forest: insert the un-collapsed moves in round order (the step's own path reversal)
-    // The child end is chosen as the step chose it when the move was played (step_child_end4: hi, unless only lo
-    // was free of un-collapsed moves), so that an imported position is bit for bit the state stepping reaches —
+    // The child end is chosen as the step chose it when the move was played (step_child_end4: lo when lo was free of
+    // un-collapsed moves, else hi), so that an imported position is bit for bit the state stepping reaches —
     // which is what lets state_key() stand for (board, moves).  "In a component then" = touched by an earlier move
     // that is still un-collapsed now: a component collapses as a whole, so a square whose old component is gone is
     // classical, and so would be every move on it.  (A move of round 8 always closes a cycle: never live.)
@@ -385,7 +385,7 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
         const u32 lo = pr & 0xFFu, hi = pr >> 8;
         if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u) {
             const u32 both = (1u << lo) | (1u << hi);
-            const u32 x = (touched & both) == (1u << hi) ? lo : hi;
+            const u32 x = ((touched >> lo) & 1u) == 0u ? lo : hi;            // step_child_end4 without a cycle
             P = step_reroot(P, Q0, x * 4u, t * 4u);                      // x becomes the child end of move t
             touched |= both;
         }

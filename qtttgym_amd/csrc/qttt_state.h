@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "qttt.h"
 
+//@isa lane
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
@@ -88,6 +89,7 @@ __device__ __forceinline__ u32 ffbl_raw(u32 x) {
 __device__ u64 *g_debug_stamps = nullptr;   // diagnostic builds only (tools/stepbench stamps)
 #endif
 
+//@isa table
 // ------------------------------------------------------------------ 3-in-a-row lookup table
 // Line table: entry m = 0x7F iff the 9-bit square mask m contains one of the 8 lines of
 // board.py:85-110 (0x7F << 23 = 1.0f), one entry per DWORD (LINE_LUT_BYTES = 2 KB) in LDS, because
@@ -117,6 +119,7 @@ __device__ inline void fill_line_lut(uint8_t *lut) {
     __syncthreads();
 }
 
+//@isa hash
 // ------------------------------------------------------------------ counter hash (the build's
 // synthetic-input spec)
 __host__ __device__ inline u32 lowbias32(u32 x) {
@@ -147,6 +150,7 @@ __device__ inline u32 collapse_bit_of(u32 x) {
     return x >> 31;
 }
 
+//@isa other
 // ------------------------------------------------------------------ native 64-bit position key
 // GameState.__hash__ / __eq__ (mcts.py:93-97) are only ever dict keys (mcts.py:160-164,210-221): what a search
 // needs is "equal keys <=> equal (board, moves)".  The packed state already is a canonical form of
@@ -164,6 +168,7 @@ __host__ __device__ inline u64 state_key(u64 P, u32 Q0) {
     return h ^ (h >> 32);
 }
 
+//@isa policy
 // ---- uniform-legal policy tables (GameState.actions rule, mcts.py:20-27, in ind2move order) ----
 // rank_pair[e][k]: the k-th pair (i < j) of e items in lexicographic order, as i | j<<4.
 // nth5[m][r] / nth4[m][r]: index of the r-th set bit of a 5-bit / 4-bit mask: the r-th set bit of the

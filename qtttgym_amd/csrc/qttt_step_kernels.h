@@ -25,6 +25,7 @@ namespace {
 // the fold of the ids' high word, and the launch key is made in the kernel (scalar unit, ~30 SALU instructions).
 // A separate instantiation, so that the kernels of the ordinary path carry neither the two extra arguments nor
 // the branch (measured: 2-3 % on a 1 M-board launch when they did).
+//@isa lane
 template <bool DEVSTEP> struct StepKeySource {};
 template <> struct StepKeySource<true> {
     const u32 *ctr;
@@ -100,6 +101,31 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     }
     ObsTiles T;
     if (OBS) T = obs_tiles<TILE_BOARDS>(otile, obs, ib);
+//@isa hash
+    // The counter hash (collapse bit; with SAMPLE the policy's word too) depends on the board id and the launch key
+    // only: it is computed HERE, while the state loads are in flight and the SIMD has nothing else to issue, and
+    // pinned in registers (the empty asm) so that the compiler does not sink it back behind the loads' wait — 8
+    // (SAMPLE: 16) VALU instructions per board off the critical path between "data landed" and "stores issued".
+    const u32 id0 = id_base + ((u32)jb + g) * BPL;                      // low 32 bits of the global board id
+    u32 hbit[BPL], hpol[BPL];
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+        hbit[k] = hpol[k] = 0u;
+        if (SAMPLE) {
+            const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
+            hpol[k] = lowbias32(h1 ^ key_hi);
+            hbit[k] = h1 >> 31;
+#ifndef QTTT_NO_HASH_HOIST                  // (A/B builds only: without the pin the compiler sinks the hash behind the loads' wait)
+            asm volatile("" : "+v"(hbit[k]), "+v"(hpol[k]));
+#endif
+        } else if (!HAS_BITS) {
+            hbit[k] = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+#ifndef QTTT_NO_HASH_HOIST
+            asm volatile("" : "+v"(hbit[k]));
+#endif
+        }
+    }
+//@isa pack
     __syncthreads();
 #ifdef QTTT_DEBUG_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -108,16 +134,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
     if (active) {
         V32 rw;
         V8 tm;
-        const u32 id0 = id_base + ((u32)jb + g) * BPL;                  // low 32 bits of the global board id
 #pragma unroll
         for (int k = 0; k < BPL; ++k) {
             u32 P0 = (u32)p.v[k], P1 = (u32)(p.v[k] >> 32);
             u32 Q0 = (u32)q.v[k], Q1 = (u32)(q.v[k] >> 32);
             u32 bit, av, win;
             if (SAMPLE) {
-                const u32 h1 = lowbias32((id0 + (u32)k) ^ key_fold);
-                const u32 h2 = lowbias32(h1 ^ key_hi);
-                bit = h1 >> 31;
+                const u32 h2 = hpol[k];
+                bit = hbit[k];
                 if (AUTO_RESET) {
                     // a finished board restarts first (empty = all zero); a board that is not done has >= 2 empty
                     // squares (8 classical squares set the done bit), so the policy always finds a legal pair,
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
             } else {
                 av = act.v[k];
                 if (HAS_BITS) bit = bt.v[k] & 1u;
-                else bit = collapse_bit_of((id0 + (u32)k) ^ key_fold);
+                else bit = hbit[k];
                 win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, av, bit, lut);
             }
             p.v[k] = (u64)P0 | ((u64)P1 << 32);
@@ -181,6 +205,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
 #endif
 }
 
+//@isa lane
 // T consecutive steps in ONE launch (qttt_step_many with QTTT_FLAG_FUSED): the boards stay in
 // registers, only the per-step streams move (2 B action in, 5 B reward/terminated out per step), so
 // the loop is VALU-bound and pays one launch instead of T.  Same results as T launches of
