@@ -52,6 +52,7 @@ __device__ __forceinline__ StepPrep step_prep(u32 P1, u32 Q1, u32 act) {
     // undefined: the count is reduced as v_lshrrev_b64 reduces it, which costs no instruction
     s.mlo = (u32)(s.comps >> (s.lo & 63u)) & SLOT_LSB;   // slot holding lo (board.py:28-33)
     s.mhi = (u32)(s.comps >> (s.hi & 63u)) & SLOT_LSB;   // slot holding hi (board.py:35-40)
+    asm("" : "+v"(s.mlo), "+v"(s.mhi));                  // (masked once: keeps the cycle test a plain two-operand AND)
     s.has_lo = s.mlo != 0u;
     s.cyc = (s.mlo & s.mhi) != 0u;                       // board.py:42: same component -> cycle
     return s;
@@ -62,8 +63,11 @@ __device__ __forceinline__ StepPrep step_prep(u32 P1, u32 Q1, u32 act) {
 // square the closing move lands on (qeval.py:35: bit 0 -> lo, 1 -> hi); otherwise either end will do: lo when lo
 // is in no component (an isolated square: no walk at all), else hi (isolated: no walk; in a component: a walk up
 // hi's tree).  ONE select on two scalar conditions.  qttt_import replays this rule (import_board).
-__device__ __forceinline__ u32 step_child_end4(const StepPrep &s, u32 bit) {
-    return ((!s.has_lo || (s.cyc && bit == 0u)) ? s.lo : s.hi) * 4u;
+// (Scalars by value, not the StepPrep: a select between two members of a struct whose address is taken is turned into
+// an indexed load from a stack copy of the struct, which the AMDGPU back end then "promotes" to 48 bytes of LDS per
+// thread — measured in expand_kernel: 17.8 -> 30.3 us per 1 M pairs.)
+__device__ __forceinline__ u32 step_child_end4(u32 lo, u32 hi, bool has_lo, bool cyc, u32 bit) {
+    return ((!has_lo || (cyc && bit == 0u)) ? lo : hi) * 4u;
 }
 
 //@isa walk
@@ -139,12 +143,14 @@ __device__ __forceinline__ u32 step_line(u32 P0, u32 &P1, const uint8_t *lut) {
     const u32 par4 = P0 & 0x44444444u;
     const u32 even4 = lshl_or<8>(P1 & 4u, __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
                                           (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4));
-    const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;                // bits 20,21 of P1 are 0
+    u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;                      // bits 20,21 of P1 are 0
+    asm("" : "+v"(cl4));    // masked ONCE: otherwise the mask is folded into three v_bitop3 with an SGPR operand (slow class)
     const u32 pc = (u32)__builtin_popcount(cl4);
-    const u32 O4 = cl4 & ~even4;
+    u32 O4 = cl4 & ~even4;
+    asm("" : "+v"(O4));                                             // (keeps the xor below a literal-operand VOP2)
     const u32 X4 = pc >= 8u ? (O4 ^ 0x7FCu) : (cl4 & even4);
-    const u32 *l32 = reinterpret_cast<const u32 *>(lut);               // a dword per mask: the byte offset is the mask "times four"
-    const u32 win = l32[X4 >> 2] | l32[O4 >> 2];
+    // a dword per mask: the byte offset is the mask "times four"
+    const u32 win = *reinterpret_cast<const u32 *>(lut + X4) | *reinterpret_cast<const u32 *>(lut + O4);
     // env.py:51: a line, or len(moves) > 8  <=>  at least 8 classical squares.  win is 0 or 0x7F,
     // pc <= 9: bit 3 of (win | pc) is the answer
     P1 = lshl_or<28>(BITOP3(win, pc, 8u, (A | B) & C), P1);
@@ -157,17 +163,30 @@ __device__ __forceinline__ u32 step_line_xo(u32 P0, u32 &P1, const uint8_t *lut)
     const u32 par4 = P0 & 0x44444444u;
     const u32 even4 = lshl_or<8>(P1 & 4u, __builtin_amdgcn_udot8(par4, 0x00008421u, 0u, false) |
                                           (__builtin_amdgcn_udot8(par4, 0x84210000u, 0u, false) << 4));
-    const u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;
+    u32 cl4 = (P1 >> (P1_CL_SHIFT - 2u)) & 0x7FCu;
+    asm("" : "+v"(cl4));
     const u32 pc = (u32)__builtin_popcount(cl4);
-    const u32 O4 = cl4 & ~even4;
+    u32 O4 = cl4 & ~even4;
+    asm("" : "+v"(O4));                                             // (keeps the xor below a literal-operand VOP2)
     const u32 X4 = pc >= 8u ? (O4 ^ 0x7FCu) : (cl4 & even4);
-    const u32 *l32 = reinterpret_cast<const u32 *>(lut);
-    const u32 wx = l32[X4 >> 2], wo = l32[O4 >> 2];
+    const u32 wx = *reinterpret_cast<const u32 *>(lut + X4), wo = *reinterpret_cast<const u32 *>(lut + O4);
     P1 = lshl_or<28>(BITOP3(wx | wo, pc, 8u, (A | B) & C), P1);      // only ever set (see step_line)
     return (wx & 1u) | ((wo & 1u) << 1);
 }
 
 //@isa reset
+// Auto-reset: a finished board (done bit) restarts empty = all zero.  The mask is made with a shift the compiler
+// cannot see through: left to itself it turns the four ANDs into a compare and four v_cndmask (five slow-class
+// instructions instead of five fast ones).
+__device__ __forceinline__ void step_auto_reset(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1) {
+    u32 gone = (u32)((int)P1 >> 31);                    // all ones iff done
+    asm("" : "+v"(gone));
+    P0 &= ~gone;
+    P1 &= ~gone;
+    Q0 &= ~gone;
+    Q1 &= ~gone;
+}
+
 // `lut` is the workgroup's LDS line table (fill_line_lut: one entry per dword, 0x7F = the mask holds a line).
 // Returns 0x7F iff a completed line exists afterwards (else 0); P1's done bit is updated.
 // TRUSTED: the caller guarantees a legal action with action[0] < action[1] (the in-kernel policy of the
@@ -176,19 +195,12 @@ template <bool AUTO_RESET, bool TRUSTED = false>
 __device__ __forceinline__ u32 step_core(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 act, u32 bit,
                                          const uint8_t *lut) {
     if (AUTO_RESET) {                                   // finished boards restart: empty = all zero
-        // the mask is made with a shift the compiler cannot see through: left to itself it turns the four ANDs into a
-        // 64-bit compare and four v_cndmask (five slow-class instructions instead of five fast ones)
-        u32 gone = (u32)((int)P1 >> 31);                // all ones iff done
-        asm("" : "+v"(gone));
-        P0 &= ~gone;
-        P1 &= ~gone;
-        Q0 &= ~gone;
-        Q1 &= ~gone;
+        step_auto_reset(P0, P1, Q0, Q1);
     }
 //@isa glue
     const StepPrep s = step_prep<TRUSTED>(P1, Q1, act);
     if (s.legal) {
-        const u64 P = step_reroot((u64)P0 | ((u64)P1 << 32), Q0, step_child_end4(s, bit), s.n6);
+        const u64 P = step_reroot((u64)P0 | ((u64)P1 << 32), Q0, step_child_end4(s.lo, s.hi, s.has_lo, s.cyc, bit), s.n6);
         P0 = (u32)P;
         P1 = (u32)(P >> 32);
         step_fields(s, P1, Q0, Q1);
@@ -208,8 +220,8 @@ __device__ __forceinline__ u32 step_core_both(u32 P0, u32 P1, u32 &Q0, u32 &Q1, 
     P1a = P1b = P1;
     if (s.legal) {
         const u64 P = (u64)P0 | ((u64)P1 << 32);
-        const u64 Pa = step_reroot(P, Q0, step_child_end4(s, 0u), s.n6);
-        const u64 Pb = s.cyc ? step_reroot(P, Q0, step_child_end4(s, 1u), s.n6) : Pa;
+        const u64 Pa = step_reroot(P, Q0, step_child_end4(s.lo, s.hi, s.has_lo, s.cyc, 0u), s.n6);
+        const u64 Pb = s.cyc ? step_reroot(P, Q0, step_child_end4(s.lo, s.hi, s.has_lo, s.cyc, 1u), s.n6) : Pa;
         u32 F = P1;                                      // the fields are the same for both children
         step_fields(s, F, Q0, Q1);
         F &= ~0x3Fu;

@@ -147,8 +147,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
                     // squares (8 classical squares set the done bit), so the policy always finds a legal pair,
                     // lo < hi by construction: the step runs TRUSTED (no validation, no sorting), as in
                     // step_random_fused_kernel
-                    const u32 keep = ~(u32)((int)P1 >> 31);
-                    P0 &= keep; P1 &= keep; Q0 &= keep; Q1 &= keep;
+                    step_auto_reset(P0, P1, Q0, Q1);
                     const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
                     av = ROWS ? policy_action_rows(prows, empty, h2) : policy_action(reinterpret_cast<const uint8_t *>(prows), empty, h2);
                     win = step_core<false, true>(P0, P1, Q0, Q1, av, bit, lut);
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
         u32 act, win;
         if (AUTO_RESET) {
-            const u32 keep = ~(u32)((int)P1 >> 31);                 // a finished board restarts: empty = all zero
-            P0 &= keep; P1 &= keep; Q0 &= keep; Q1 &= keep;
+            step_auto_reset(P0, P1, Q0, Q1);                        // a finished board restarts: empty = all zero
             const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;        // >= 2 squares: the board is not done
             act = policy_action_nth9(plut, nth9, empty, h2);
             win = step_core<false, true>(P0, P1, Q0, Q1, act, h1 >> 31, lut);
