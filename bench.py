@@ -408,8 +408,10 @@ class Workload:
             ev_s.append(e)
             wall_s.append(w)
         self.replay_ok = bool(self.torch.equal(self.env.state, self.final_state))
-        # MAX over ranks of each rank's median region
-        return all_max(median(ev_s)), all_max(min(ev_s)), all_max(median(wall_s)), R
+        # this rank's own numbers (reported per rank in the N > 1 line) ...
+        self.rank_median_s, self.rank_best_s, self.rank_wall_s = median(ev_s), min(ev_s), median(wall_s)
+        # ... and the MAX over ranks of each rank's median region: what `value` is made from
+        return all_max(self.rank_median_s), all_max(self.rank_best_s), all_max(self.rank_wall_s), R
 
 
 def run_legs(torch, dev, args):
@@ -555,6 +557,23 @@ def config5_leg(torch, dev, args, n=65536, K=50):
 
 
 # ---------------------------------------------------------------------------- one rank
+CPU_AFFINITY = None
+
+
+def bind_cpu(args):
+    """Bind this rank to the cores local to its GPU (sysfs only: nothing here touches HIP).  QTTT_BENCH_NO_BIND=1 skips it.
+    The result goes into config.cpu_affinity."""
+    global CPU_AFFINITY
+    from qtttgym_amd.affinity import bind_to_gpu
+    if os.environ.get("QTTT_BENCH_NO_BIND") == "1":
+        CPU_AFFINITY = {"bound": False, "reason": "QTTT_BENCH_NO_BIND=1"}
+        return
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # several gloo ranks rehearsing on one card all map to device local_rank % n_dev; without HIP the device count is not
+    # known here, so an index past the topology simply reports "not found" and binds nothing
+    CPU_AFFINITY = bind_to_gpu(local_rank)
+
+
 def run(args):
     import torch
     import torch.distributed as dist
@@ -566,6 +585,7 @@ def run(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    affinity = CPU_AFFINITY          # made in main(), before torch was imported
     # one rank per GPU; QTTT_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (plumbing only)
     backend = os.environ.get("QTTT_DIST_BACKEND", "nccl")
     n_dev = torch.cuda.device_count()
@@ -623,6 +643,17 @@ def run(args):
     ev_med, ev_min, wall_med, R = wl.measure(barrier, all_max, regions=args.regions)
     replay_ok = wl.replay_ok
     term_count, win_count = wl.term_count, wl.win_count
+    from qtttgym_amd.dist import gather_rank_values, agree
+    # what each rank measured by itself (value / ms_per_step above are the MAX over ranks of the medians): the first
+    # thing to look at when N GPUs give less than N x.  One all_gather of three doubles, the same kind of collective as
+    # the all_max inside measure(); a failure leaves None in the line, never takes the value with it.
+    per_rank = None
+    try:
+        rows = gather_rank_values([wl.rank_median_s, wl.rank_best_s, wl.rank_wall_s], coll_dev if use_dist else None)
+        per_rank = {"ms_per_step": [r[0] / K * 1e3 for r in rows], "best_region_ms_per_step": [r[1] / K * 1e3 for r in rows],
+                    "host_wall_ms_per_step": [r[2] * 1e3 / K for r in rows]}
+    except Exception as e:                                       # noqa: BLE001
+        sys.stderr.write("bench.py: per-rank timing all_gather failed on rank %d: %r\n" % (rank, e))
 
     gather = None
     if use_dist:
@@ -630,6 +661,9 @@ def run(args):
         # any of it — e.g. the very first RCCL gather on a node this code has never seen — is reported inside the
         # line and never takes the scaling value down with it.
         # episode counters: once per run
+        # Each optional collective is entered by ALL ranks or by none: a rank that fails while PREPARING one says so in a
+        # one-flag all_reduce(MIN) first (dist.agree), so the others do not block in a gather it never joins.  (A rank
+        # that dies INSIDE a collective cannot be helped from here: bench.py's launcher deadline ends the job.)
         try:
             cnt = torch.stack([term_count, win_count]).to(coll_dev)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -641,11 +675,21 @@ def run(args):
         if os.environ.get("QTTT_BENCH_NO_GATHER") == "1":
             gather = {"skipped": "QTTT_BENCH_NO_GATHER=1"}
         else:
+            ret, prep_error = None, None
             try:
                 from qtttgym_amd.dist import gather_returns
-                if os.environ.get("QTTT_BENCH_FAIL_GATHER") == "1":      # test hook (tests/test_round4_gpu.py)
-                    raise RuntimeError("QTTT_BENCH_FAIL_GATHER=1: injected failure of the returns gather")
+                fail = os.environ.get("QTTT_BENCH_FAIL_GATHER")          # test hooks (tests/test_round4_gpu.py, test_round5_gpu.py)
+                if fail == "1" or (fail is not None and fail.startswith("rank") and int(fail[4:]) == rank):
+                    raise RuntimeError("QTTT_BENCH_FAIL_GATHER=%s: injected failure of the returns gather" % fail)
                 ret = env._reward.clone().to(coll_dev)
+            except Exception as e:                               # noqa: BLE001
+                prep_error = e
+                sys.stderr.write("bench.py: returns gather could not be prepared on rank %d: %r\n" % (rank, e))
+            try:
+                if not agree(prep_error is None, coll_dev):
+                    raise RuntimeError("skipped on every rank: %s" % ("this rank failed to prepare it: %s: %s"
+                                       % (type(prep_error).__name__, prep_error) if prep_error is not None else
+                                       "another rank failed to prepare it"))
                 gather_returns(ret, dst=0)                           # untimed: connection set-up of the gather
                 torch.cuda.synchronize(dev)
                 barrier()
@@ -683,6 +727,12 @@ def run(args):
                          "(max over ranks); value, ms_per_step and roofline all use it" % R,
                 "regions": R, "host_wall_ms_per_step": wall_med * 1e3 / K, "returns_gather": gather,
                 "best_region_ms_per_step": ev_min * 1e3 / K,
+                # each rank's own median / best region and host wall time per step, in rank order, and who set the value
+                "per_rank_ms_per_step": None if per_rank is None else per_rank["ms_per_step"],
+                "per_rank_best_region_ms_per_step": None if per_rank is None else per_rank["best_region_ms_per_step"],
+                "per_rank_host_wall_ms_per_step": None if per_rank is None else per_rank["host_wall_ms_per_step"],
+                "slowest_rank": None if per_rank is None else max(range(len(per_rank["ms_per_step"])), key=lambda r: per_rank["ms_per_step"][r]),
+                "rank_spread": None if per_rank is None else max(per_rank["ms_per_step"]) / max(min(per_rank["ms_per_step"]), 1e-12),
                 "config": {"workload": "%d boards %s, uniform-legal random policy, auto-reset, %s"
                                        % (total if strong else B, "sharded over %d GPUs" % world if strong else "per GPU", what),
                            "boards_per_gpu": B, "boards_total": total, "state_bytes_per_board": state_bytes,
@@ -690,6 +740,7 @@ def run(args):
                            "dist_backend": backend if use_dist else None,
                            "self_launched": bool(os.environ.get("QTTT_BENCH_SELF_LAUNCHED")),
                            "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                           "cpu_affinity": affinity,                      # rank 0's (every rank binds to its own GPU's cores)
                            "board_offset_last_rank": shard_range(total, world - 1, world)[0] if strong else (world - 1) * B,
                            "replay_matches_recording": replay_ok,
                            "episodes_finished": int(term_count), "steps_with_line": int(win_count)},
@@ -707,6 +758,9 @@ def run(args):
                              # traffic, not HBM traffic.  The same kernel with a working set that cannot be cached
                              # (the 16 M-board leg, filled in below when the legs run):
                              "state_resident_in_infinity_cache": bool(B * algo_bytes <= 256 << 20),
+                             # scalars (a driver that keeps only scalar fields of this object still sees them)
+                             "beyond_cache_boards": None, "beyond_cache_launch_us": None, "beyond_cache_frac": None,
+                             "beyond_cache_frac_of_achievable": None,
                              "beyond_cache": None},
             }
             actions = wl.actions
@@ -719,10 +773,27 @@ def run(args):
                         "boards": big[0]["boards"], "launch_us": big[0]["us_per_step"], "achieved": big[0]["achieved_GBps"],
                         "frac": big[0]["frac"], "frac_of_achievable": big[0]["achieved_GBps"] / HBM_ACHIEVABLE_GBS,
                         "kernel": big[0]["kernel"], "working_set_MB": big[0]["boards"] * state_bytes / 1e6}
+                    out["roofline"].update(beyond_cache_boards=big[0]["boards"], beyond_cache_launch_us=big[0]["us_per_step"],
+                                           beyond_cache_frac=big[0]["frac"],
+                                           beyond_cache_frac_of_achievable=big[0]["achieved_GBps"] / HBM_ACHIEVABLE_GBS)
             if not args.no_cpu_baseline and world == 1:                 # rank 0 at N = 1 only
                 # bounded sample: the first <=256 recorded steps of every board of rank 0, ~15 s of CPU
                 t_cpu = min(K + W, 256)
                 out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed, args.cpu_budget)
+            if "legs" in out:
+                # LAST in the object, so that a stored tail of the line still carries them: BASELINE configs 2 / 3 / 5 and
+                # the beyond-cache fraction as plain scalars ("report both")
+                L = {l["name"]: l for l in out["legs"]}
+                g = lambda name, key: (L[name].get(key) if name in L else None)
+                out["configs"] = {
+                    "config1_us": launch_s * 1e6, "config1_frac": achieved / HBM_PEAK_GBS,
+                    "config2_us": g("config2_4096_boards", "us_per_step"), "config2_frac": g("config2_4096_boards", "frac"),
+                    "config3_us": g("config3_262144_boards", "us_per_step"), "config3_frac": g("config3_262144_boards", "frac"),
+                    "config3_fused_us": g("random_fused_262144_boards", "us_per_step"),
+                    "config5_us": g("config5_expand_rollout_65536_pairs", "us_per_unit"),
+                    "config5_frac": g("config5_expand_rollout_65536_pairs", "frac"),
+                    "beyond_cache_us": g("beyond_infinity_cache_16777216_boards", "us_per_step"),
+                    "beyond_cache_frac": g("beyond_infinity_cache_16777216_boards", "frac")}
             print(json.dumps(out), flush=True)
     if use_dist:
         barrier()
@@ -757,6 +828,7 @@ def main():
         raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1, --total-boards >= --gpus")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # before anything imports torch or touches the GPU
+    bind_cpu(args)                           # likewise: sysfs + sched_setaffinity only
     sys.exit(run(args))
 
 

@@ -17,6 +17,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qtttgym_amd import VecEnv  # noqa: E402
+from qtttgym_amd import recommended_env  # noqa: E402
+recommended_env(apply=True)   # HIP_FORCE_DEV_KERNARG=1 etc., before the first HIP call
 from qtttgym_amd.actions import action36_to_pairs  # noqa: E402  (ind2move for a whole batch, mcts.py:339-343)
 
 

@@ -153,9 +153,18 @@ int qttt_board_op(const void *records_in, void *records_out, int64_t n, void *st
 int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, void *stream);
 /* The same for records that live in HOST-accessible pinned memory (what the Board façade owns): completion is detected
  * by polling a stamp the kernel writes into byte 63 of every out record once the record is visible system-wide —
- * 9.7 us per single-record call instead of 14.7 - 16.0 through hipStreamSynchronize.  Byte 63 of the out records is
- * cleared by the call and is 1 on return.  Falls back to synchronising the stream for more than 256 records or when a
- * poll has not ended after ~2 ms.  records_out MUST be dereferenceable by the host. */
+ * 9.7 us per single-record call instead of 14.7 - 16.0 through hipStreamSynchronize.  For n <= 256 records byte 63 of
+ * every out record is cleared by the call and is 1 on return; a poll that has not ended after ~2 ms (e.g. a long kernel
+ * queued ahead on the stream) falls back to synchronising the stream — the records are complete and stamped on return
+ * either way.  For n > 256 the call does not poll at all: it synchronises the stream, and byte 63 is neither cleared nor
+ * stamped (whatever the caller left there stays).  records_out MUST be dereferenceable by the host.
+ * n == 1 goes through a BOUNDED MAILBOX instead of a launch: one resident wave on a private non-blocking stream serves a
+ * pinned request slot (record copied in, request number written last, answer polled) — Env.step 10.8 us / Board.make_move
+ * 7.1 us per call against 17.8 / 12.4 through a launch (profiles/r05/facade_latency*.json; the reference's own Env.step,
+ * env.py:34-53, takes ~12 us).  The wave leaves BY ITSELF after QTTT_BOARD_MAILBOX_US microseconds without a request
+ * (default 100, capped at 200; 0 disables the mailbox) and is launched again by the next call; a DEVICE-wide synchronise
+ * issued inside that window waits for it to leave, stream-level synchronisation does not.  `stream` is not used on this
+ * path (host records have no device-side producer to be ordered after); results are identical on both paths. */
 int qttt_board_op_host(const void *records_in, void *records_out, int64_t n, void *stream);
 
 /* Synthetic policy for measurement: uniform over legal unordered pairs

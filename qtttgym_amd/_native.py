@@ -4,9 +4,6 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# Kernel arguments in device memory: ROCm 7.2's default on MI355X, worth 1.2 us per launch; made explicit
-# for processes that import the package before anything initialises HIP (it is read when the runtime starts).
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # QTTT_LIB_PATH: load another build of the same ABI (A/B diagnostics); default = the in-tree build
 LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.so")
 
@@ -66,6 +63,28 @@ SIGNATURES = {
 }
 
 _lib = None
+
+# Process settings the measurements of this repo were made with.  Importing the package does NOT touch os.environ
+# (an embedding host owns its environment): a launcher calls recommended_env(apply=True) before anything initialises
+# HIP, or exports the variables itself.  INTEGRATION.md §3.
+RECOMMENDED_ENV = {
+    # kernel arguments placed in device memory: ROCm 7.2's default on MI355X, read when the HIP runtime starts.  Worth
+    # 1.2 us per launch (tools/stepbench, profiles/r04/kernarg_placement.txt: 7.13 us with it, 8.32 without at 1 M
+    # boards; 3.80 / 4.77 at 262 144)
+    "HIP_FORCE_DEV_KERNARG": "1",
+    # multi-process RCCL / tensor sharing on this pool needs dmabuf IPC
+    "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+}
+
+
+def recommended_env(apply=False):
+    """The environment variables bench.py / the examples run with, as a dict.  apply=True sets those that the process
+    has not set itself (os.environ.setdefault) — call it before the first HIP call (torch.cuda.*, lib()): the HIP
+    runtime reads them once, when it starts."""
+    if apply:
+        for k, v in RECOMMENDED_ENV.items():
+            os.environ.setdefault(k, v)
+    return dict(RECOMMENDED_ENV)
 
 
 def flag_shape(boards_per_lane=0, workgroup_size=0):

@@ -13,6 +13,8 @@ in `Board.make_moves`, which ships n records through one launch.
 Thread-safety: the pinned staging records are shared by every Board of the process and guarded by a lock;
 a Board object itself is a plain mutable Python object, as in the reference.
 """
+import ctypes
+import os
 import random
 import threading
 
@@ -20,6 +22,12 @@ import torch
 
 from . import _native
 from .vec_env import _raw_stream
+
+try:                                              # optional host-side accelerator (csrc/fastboard.c); never a compute path
+    from . import _fastboard
+except ImportError:
+    _fastboard = None
+_current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 
 
 class QEvalClassic:
@@ -52,10 +60,18 @@ class QEvalClassic:
         return out
 
 
+def _device_eval(qeval):
+    """True iff the collapse may run in the HIP kernel: the evaluator's `eval` IS QEvalClassic.eval (the class itself or a
+    subclass that does not override it).  Anything else — an unrelated class, or a QEvalClassic subclass with its own
+    `eval` — is the reference's plug point (board.py:2,7,51) and decides the collapse on the host."""
+    return getattr(type(qeval), "eval", None) is QEvalClassic.eval
+
+
 class _Staging:
     """One 64-byte record in and one out (include/qttt.h: qttt_board_op), both in pinned host memory
-    that the kernel reads and writes directly: a Board call is one kernel launch and one stream
-    synchronise — no host-to-device or device-to-host copy calls at all."""
+    that the kernel reads and writes directly: a Board call is one kernel launch and a poll of the out
+    record's completion stamp (qttt_board_op_host; it synchronises the stream only for more than 256
+    records or when the poll has not ended after ~2 ms) — no host-to-device or device-to-host copy calls."""
 
     def __init__(self):
         if not torch.cuda.is_available():
@@ -66,6 +82,14 @@ class _Staging:
         self.op_sync = self.lib.qttt_board_op_host         # pinned records: poll the stamp, no stream synchronise
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._alloc(64)
+        # The bookkeeping around the call (pack / adopt below) in C when qtttgym_amd/_fastboard.so is built
+        # (csrc/fastboard.c, __graft_entry__.build()): same attributes, same aliasing, ~4 us less per call.  It works on
+        # the FIRST record of the pinned buffers, so it is re-initialised whenever they are re-allocated.
+        self.fast = None
+        if _fastboard is not None and os.environ.get("QTTT_NO_FASTBOARD") != "1":
+            self._fn_addr = ctypes.cast(self.lib.qttt_board_op_host, ctypes.c_void_p).value
+            _fastboard.init(self._fn_addr, self.p_in, self.p_out)
+            self.fast = _fastboard.board_op
 
     def _alloc(self, n_records):
         nb = _native.BOARD_RECORD_BYTES * n_records
@@ -75,6 +99,8 @@ class _Staging:
         self.a_out = self.t_out.numpy()
         self.m_in = memoryview(self.a_in)
         self.p_in, self.p_out = self.t_in.data_ptr(), self.t_out.data_ptr()
+        if getattr(self, "fast", None) is not None:
+            _fastboard.init(self._fn_addr, self.p_in, self.p_out)
 
     @staticmethod
     def pack(board, op, lo=0, hi=0, bit=0, drop_last_move=False):
@@ -195,7 +221,15 @@ class Board:
 
     def _make_move_device(self, lo, hi, bit, autofill=True, drop_last_move=False):
         op = _native.OP_MAKE_MOVE if autofill else _native.OP_UPDATE_QSTRUCTS
-        self._adopt(_stage().run(self, op, lo, hi, bit, drop_last_move))
+        st = _stage()
+        if st.fast is not None and _current_device() == st.device.index:
+            with st.lock:                                          # the one staging record: one caller at a time
+                rc = st.fast(self, op, lo, hi, bit, drop_last_move, _raw_stream(st.device.index))
+            if rc == 0:
+                return
+            if rc != -100:                                         # -100: an attribute of an unusual type, the Python path below
+                _native.check(rc, "qttt_board_op_host")
+        self._adopt(st.run(self, op, lo, hi, bit, drop_last_move))
 
     @classmethod
     def from_export(cls, ex, index=0, qevaluator=None):
@@ -236,7 +270,7 @@ class Board:
     def make_move(self, move):
         """board.py:9-25, same exceptions with the same messages, raised before any mutation."""
         lo, hi, cycle, m0 = self._validate(move)
-        if cycle and not isinstance(self.qeval, QEvalClassic):
+        if cycle and not _device_eval(self.qeval):
             return self._make_move_custom_eval(lo, hi, m0)
         bit = 0
         if cycle:
@@ -266,7 +300,7 @@ class Board:
                     raise
                 result[i] = e
                 continue
-            if cycle and not isinstance(b.qeval, QEvalClassic):
+            if cycle and not _device_eval(b.qeval):
                 b._make_move_custom_eval(lo, hi, m0)
                 continue
             bit = 0
@@ -314,7 +348,7 @@ class Board:
             if hi in s:
                 m1 = j
                 break
-        if m0 == m1 and not isinstance(self.qeval, QEvalClassic):
+        if m0 == m1 and not _device_eval(self.qeval):
             self.moves.pop()                                       # _make_move_custom_eval appends it again
             return self._make_move_custom_eval(lo, hi, m0, autofill=False)
         bit = 0

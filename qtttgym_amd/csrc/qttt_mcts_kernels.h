@@ -215,7 +215,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     int8_t *result, uint8_t *plies, u64 *fP, u64 *fQ, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    __shared__ uint8_t nth9[512 * 9];
+    __shared__ uint8_t nth9[NTH9_BYTES];
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
     fill_policy_lut<QTTT_BLOCK>(plut);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_many_kernel(
     int8_t *result, uint8_t *plies, int64_t n_lanes) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    __shared__ uint8_t nth9[512 * 9];
+    __shared__ uint8_t nth9[NTH9_BYTES];
     const int64_t j = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     const int64_t jl = j < n_lanes ? j : 0;
     const int64_t i = jl / n_sims;                        // board
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
     int32_t *value_sum, int8_t *result, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    __shared__ uint8_t nth9[512 * 9];
+    __shared__ uint8_t nth9[NTH9_BYTES];
     __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
     __shared__ u64 ltbl[512];
     __shared__ int acc[BLOCK];                                  // [pair of the workgroup][child]
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
     static_assert(BLOCK >= XR_MAX_PAIRS, "one pair per lane in the expansion phase");
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    __shared__ uint8_t nth9[512 * 9];
+    __shared__ uint8_t nth9[NTH9_BYTES];
     __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
     __shared__ u64 ltbl[512];
     __shared__ u64 kidPs[XR_MAX_PAIRS * 2];                     // [pair][child] plane-P word; plane Q is the same for both

@@ -225,7 +225,10 @@ __device__ __forceinline__ u32 policy_action(const uint8_t *plut, u32 empty, u32
 
 // nth9[m * 9 + r] = the r-th empty square of the 9-bit mask m: kernels that run the policy for many plies per
 // board (rollout, fused random stepping) use this full table (4.5 KB, computed here: thread m writes row m)
-// instead of the two-level lookup of policy_nth()
+// instead of the two-level lookup of policy_nth(); behind it, nth9[NTH9_PAIRS + m] = the number of unordered pairs of
+// the empty squares of m, e (e - 1) / 2 (one LDS read at a constant offset from the mask instead of a second
+// popcount, a multiply and a shift per ply).
+constexpr u32 NTH9_PAIRS = 512u * 9u, NTH9_BYTES = NTH9_PAIRS + 512u;
 template <int BLOCK>
 __device__ inline void fill_nth9(uint8_t *nth9) {
     for (u32 m = threadIdx.x; m < 512u; m += BLOCK) {
@@ -235,6 +238,7 @@ __device__ inline void fill_nth9(uint8_t *nth9) {
             nth9[m * 9u + r] = (uint8_t)v;                 // kept only if bit v is set (r advances), else overwritten
             r += m >> v & 1u;                              // r <= v inside the loop: the store stays in row m
         }
+        nth9[NTH9_PAIRS + m] = (uint8_t)((r * (r - 1u)) >> 1);
     }
 }
 // The one-launch-per-step policy kernel keeps the same information as ONE word per mask: nibble r of row32[m] = the
@@ -278,7 +282,7 @@ __device__ __forceinline__ u32 policy_action_rows(const u32 *rows, u32 empty, u3
 // the policy's action for the empty-square mask `empty` (>= 2 squares) from hash word h2: lo | hi << 8
 __device__ __forceinline__ u32 policy_action_nth9(const uint8_t *plut, const uint8_t *nth9, u32 empty, u32 h2) {
     const u32 e = (u32)__builtin_popcount(empty);
-    const u32 ij = plut[e * 36u + __umulhi(h2, (e * (e - 1u)) >> 1)];
+    const u32 ij = plut[e * 36u + __umulhi(h2, (u32)nth9[NTH9_PAIRS + empty])];
     return (u32)nth9[empty * 9u + (ij & 0xFu)] | ((u32)nth9[empty * 9u + (ij >> 4)] << 8);
 }
 

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     int64_t out_stride, int64_t n, int32_t n_steps, float *__restrict__ returns) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    __shared__ uint8_t nth9[512 * 9];
+    __shared__ uint8_t nth9[NTH9_BYTES];
     const int64_t ib = (int64_t)blockIdx.x * BLOCK;                 // first board of the workgroup (block-uniform)
     const int64_t i = ib + threadIdx.x;
     const bool active = i < n;

@@ -90,3 +90,25 @@ def gather_returns(local_returns, dst=0):
     if rank != dst:
         return None
     return torch.cat([o[:s] for o, s in zip(out, sizes)])
+
+
+def gather_rank_values(values, device=None):
+    """all_gather of a few floats per rank (timings): returns [[rank 0's values], [rank 1's], ...] on every rank.
+    One tiny collective, same shape on every rank; a single-rank job returns [values]."""
+    vals = [float(v) for v in values]
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [vals]
+    t = torch.tensor(vals, dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu()] for o in out]
+
+
+def agree(ok, device=None):
+    """True iff EVERY rank passes ok=True (one all_reduce(MIN) of a flag).  Lets the ranks skip an optional collective
+    together when one of them failed while preparing it — instead of the others blocking in it."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t[0]))

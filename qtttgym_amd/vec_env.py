@@ -422,7 +422,15 @@ class VecEnv:
     # ------------------------------------------------------------------ MCTS-side rows
     @classmethod
     def from_state(cls, state, num_envs, seed=0, auto_reset=False, board_offset=0):
-        """Wraps an existing packed state tensor (e.g. a child buffer written by expand())."""
+        """Wraps an existing packed state tensor (e.g. a child buffer written by expand()).
+
+        The tensor must hold states this library wrote (reset, step, expand, import_boards ...).  Two things are relied
+        on and NOT re-checked: the cached qstructs and rooted forest are consistent with the moves, and the done bit
+        (bit 63 of plane P) is set iff the board has a completed line or at least eight classical squares — the step
+        only ever SETS that bit (a line stays a line), and with auto_reset the in-kernel policy trusts "not done" to
+        mean "at least two empty squares".  A hand-made tensor with a wrong done bit is stepped without faults (the
+        kernels keep everything in registers, every loop is bounded) but gives states the reference never reaches;
+        to bring boards from attributes use import_boards(), which computes the bit."""
         env = cls.__new__(cls)
         env.num_envs = int(num_envs)
         env.device = state.device
@@ -515,11 +523,16 @@ class VecEnv:
         else:                                       # the per-child rows are optional: only what the dict holds is computed
             sd = self.state.device
             for c in ("child0", "child1"):
+                if c not in out:
+                    raise ValueError("out[%r] is required" % c)
                 if out[c].num_envs != n or out[c].state.device != sd:
                     raise ValueError("out[%r] must be a VecEnv of N boards on this device" % c)
-            required = tuple(k for k, _, _ in extra)
+            required = tuple(k for k, _, _ in extra) + (("key",) if python_key else ())
             for k, dt, shp in self._EXPAND_ROWS + tuple(extra) + (("key", torch.int64, (2,)),):
-                if k in out or k in required:
+                if k in required and k not in out:
+                    # e.g. the dict of expand() handed to expand_rollout(), or python_key=True with a dict made without it
+                    raise ValueError("out[%r] is required" % k)
+                if k in out:
                     _check_out(out[k], dt, (n,) + shp, sd, "out[%r]" % k)
         return out
 
@@ -531,16 +544,17 @@ class VecEnv:
             raise ValueError("action36 must have shape (%d,)" % self.num_envs)
         return a
 
-    def expand(self, action36, out=None, python_key=True):
+    def expand(self, action36, out=None, python_key=None):
         """MCTS._step (mcts.py:233-267) for every board: action36 u8[N] (ind2move index).
         Returns dict(child0, child1 = VecEnv over the child states, n_children u8[N],
         winner i8[N,2], terminal bool[N,2], legal int64[N,2], state_key int64[N,2] and — with python_key —
         key int64[N,2] = Python's hash of each child, see node_info).
         `out` = the dict of an earlier call: its child states and tensors are overwritten (a search loop
-        then allocates nothing per expansion); its "key" entry decides python_key."""
+        then allocates nothing per expansion); its "key" entry decides python_key (python_key=True with a dict
+        that has no "key" entry raises ValueError).  python_key=None: True for a fresh dict, the dict's choice otherwise."""
         n = self.num_envs
         a = self._as_action36(action36)
-        out = self._expand_out(out, python_key)
+        out = self._expand_out(out, (out is None) if python_key is None else bool(python_key))
         rc = self._launch(self._lib.qttt_expand, self.state.data_ptr(), a.data_ptr(), out["child0"].state.data_ptr(),
                           out["child1"].state.data_ptr(), _ptr(out.get("n_children")), _ptr(out.get("winner")),
                           _ptr(out.get("terminal")), _ptr(out.get("legal")), _ptr(out.get("key")),
@@ -548,7 +562,7 @@ class VecEnv:
         _native.check(rc, "qttt_expand")
         return out
 
-    def expand_rollout(self, action36, n_sims=1, step_idx0=None, out=None, python_key=False, with_result=False):
+    def expand_rollout(self, action36, n_sims=1, step_idx0=None, out=None, python_key=None, with_result=False):
         """One MCTS._rollout below the selected node in ONE launch (mcts.py:166-176,210-221,233-267): expand() plus
         n_sims random playouts from EACH child.  Returns expand()'s dict with two more entries:
         value_sum int32[N,2] = the sum over a child's playouts of `r if leaf.turn else -r` (mcts.py:174; divide by
@@ -564,7 +578,7 @@ class VecEnv:
         a = self._as_action36(action36)
         with_result = with_result or (out is not None and "result" in out)
         extra = (("value_sum", torch.int32, (2,)),) + ((("result", torch.int8, (2, S)),) if with_result else ())
-        out = self._expand_out(out, python_key, extra)
+        out = self._expand_out(out, bool(python_key), extra)       # None = False for a fresh dict, the dict's choice otherwise
         rc = self._launch(self._lib.qttt_expand_rollout, self.state.data_ptr(), a.data_ptr(),
                           out["child0"].state.data_ptr(), out["child1"].state.data_ptr(), _ptr(out.get("n_children")),
                           _ptr(out.get("winner")), _ptr(out.get("terminal")), _ptr(out.get("legal")),

@@ -136,6 +136,42 @@ def test_custom_evaluator_plug_point():
     assert ev.seen == [(0, 1, 0), (0, 1, 1)]
     assert b.board[:2] == [1, 0] and b.qstructs == []
 
+    # a SUBCLASS of QEvalClassic that overrides .eval is the same plug point (the rule is "whose eval is it", not
+    # isinstance): its answer is applied verbatim, on make_move, make_moves and update_qstructs alike
+    from qtttgym_amd import QEvalClassic
+
+    class Contrary(QEvalClassic):
+        def __init__(self):
+            self.calls = 0
+
+        def eval(self, entangled):
+            self.calls += 1
+            return [m[1] if i % 2 == 0 else m[0] for i, m in enumerate(entangled)]     # move 0 on its hi, move 1 on its lo
+
+    ev2 = Contrary()
+    b2 = Board(ev2)
+    b2.make_move((3, 5))
+    b2.make_move((5, 3))
+    assert ev2.calls == 1 and b2.board[3] == 1 and b2.board[5] == 0 and b2.qstructs == []
+    b3 = Board(ev2)
+    b3.make_move((0, 8))
+    assert Board.make_moves([b3], [(0, 8)]) == [None] and ev2.calls == 2 and b3.board[8] == 0 and b3.board[0] == 1
+    b4 = Board(ev2)
+    b4.make_move((1, 2))
+    b4.moves.append((1, 2, 1))
+    b4.update_qstructs((1, 2))
+    assert ev2.calls == 3 and b4.board[2] == 0 and b4.board[1] == 1
+
+    # ... while a subclass that only overrides the DRAW (qeval.py:35) stays on the device path
+    class AlwaysHi(QEvalClassic):
+        def choose(self, lo, hi):
+            return hi
+
+    b5 = Board(AlwaysHi())
+    b5.make_move((4, 6))
+    b5.make_move((4, 6))
+    assert b5.board[6] == 1 and b5.board[4] == 0
+
 
 def test_vecenv_render_and_turn(capsys):
     from qtttgym_amd import VecEnv

@@ -1,0 +1,212 @@
+"""Round 5, GPU side: the N > 1 line explains itself (per-rank timings, CPU binding), the driver's command shape
+rehearsed with as many gloo ranks as one card may host, an asymmetric failure of the optional gather, and the tail of
+the JSON line carrying BASELINE configs 2 / 3 / 5 and the beyond-cache fraction."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The GPU boxes of this pool allow at most 6 processes on a card at once: the driver-shaped N = 8 command is rehearsed
+# with 6 ranks here; its eight-rank bookkeeping runs on CPU gloo ranks in tests/test_round5_cpu.py.
+RANKS_ON_ONE_CARD = 6
+
+
+def bench(*args, env=None, check=True):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=900, env=e)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if check:
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert len(lines) == 1, out.stdout
+    return out, lines
+
+
+@pytest.mark.timeout(900)
+def test_driver_shape_with_six_gloo_ranks_on_the_one_card():
+    """`python bench.py --gpus N --steps 20 --warmup 5` as the driver runs it (self-launched ranks, no torchrun), N = 6
+    ranks sharing the one GPU over gloo: every rank is in the line, in rank order."""
+    n = RANKS_ON_ONE_CARD
+    out, lines = bench("--gpus", str(n), "--steps", "20", "--warmup", "5", "--boards", "131072",
+                       env={"QTTT_DIST_BACKEND": "gloo"})
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n == d["ranks_seen"] and d["scaling"] == "weak" and d["config"]["self_launched"] is True
+    assert d["config"]["boards_total"] == n * 131072 and d["config"]["board_offset_last_rank"] == (n - 1) * 131072
+    assert d["config"]["replay_matches_recording"] is True
+    pr = d["per_rank_ms_per_step"]
+    assert isinstance(pr, list) and len(pr) == n and all(x > 0 for x in pr)
+    assert len(d["per_rank_best_region_ms_per_step"]) == n and len(d["per_rank_host_wall_ms_per_step"]) == n
+    # value is made from the slowest rank's median region
+    assert d["slowest_rank"] == max(range(n), key=lambda r: pr[r])
+    assert abs(max(pr) - d["ms_per_step"]) < 1e-12 and abs(d["rank_spread"] - max(pr) / min(pr)) < 1e-9
+    assert abs(d["value"] - n * 131072 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    assert all(b <= m + 1e-12 for b, m in zip(d["per_rank_best_region_ms_per_step"], pr))
+    a = d["config"]["cpu_affinity"]
+    assert isinstance(a, dict) and a["bound"] in (True, False) and (a["bound"] or a["reason"])
+    assert d["returns_gather"]["boards_gathered"] == n * 131072
+
+
+def test_single_rank_line_has_the_per_rank_fields_too():
+    out, lines = bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs")
+    d = json.loads(lines[0])
+    assert d["per_rank_ms_per_step"] == [d["ms_per_step"]] and d["slowest_rank"] == 0 and d["rank_spread"] == 1.0
+    assert "cpu_affinity" in d["config"]
+    out, lines = bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs",
+                       env={"QTTT_BENCH_NO_BIND": "1"})
+    assert json.loads(lines[0])["config"]["cpu_affinity"] == {"bound": False, "reason": "QTTT_BENCH_NO_BIND=1"}
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_failing_to_prepare_the_gather_does_not_hang_the_others():
+    """an ASYMMETRIC failure (rank 1 only) in front of the optional returns gather — every rank skips the
+    gather together (dist.agree), the line is printed with the value, the error is in it."""
+    out, lines = bench("--gpus", "2", "--boards", "16384", "--steps", "10", "--warmup", "2",
+                       env={"QTTT_DIST_BACKEND": "gloo", "QTTT_BENCH_FAIL_GATHER": "rank1", "QTTT_BENCH_TIMEOUT": "300"})
+    d = json.loads(lines[0])
+    assert d["ranks_seen"] == 2 and d["value"] > 0 and len(d["per_rank_ms_per_step"]) == 2
+    assert "error" in d["returns_gather"] and "another rank" in d["returns_gather"]["error"]
+    assert "injected failure" in out.stderr
+
+
+@pytest.mark.timeout(900)
+def test_the_tail_of_the_default_line_carries_the_baseline_configs():
+    """a driver that stores only the tail of the (14 KB) line, or only scalar fields of `roofline`, still
+    sees BASELINE configs 2 / 3 / 5 and the beyond-cache fraction."""
+    out, lines = bench("--cpu-budget", "2")
+    line = lines[0]
+    tail = line[-600:]
+    for k in ("config2_us", "config3_us", "config3_frac", "config5_us", "beyond_cache_frac"):
+        assert '"%s"' % k in tail, (k, tail)
+    d = json.loads(line)
+    assert list(d)[-1] == "configs"                                   # after legs and cpu_baseline
+    r, c = d["roofline"], d["configs"]
+    legs = {l["name"]: l for l in d["legs"]}
+    assert r["beyond_cache_frac"] == r["beyond_cache"]["frac"] == c["beyond_cache_frac"] == legs["beyond_infinity_cache_16777216_boards"]["frac"]
+    assert r["beyond_cache_boards"] == 16777216 and r["beyond_cache_launch_us"] == legs["beyond_infinity_cache_16777216_boards"]["us_per_step"]
+    assert all(isinstance(r[k], (int, float)) for k in ("beyond_cache_boards", "beyond_cache_launch_us", "beyond_cache_frac",
+                                                         "beyond_cache_frac_of_achievable"))
+    assert c["config2_us"] == legs["config2_4096_boards"]["us_per_step"] and c["config3_us"] == legs["config3_262144_boards"]["us_per_step"]
+    assert c["config5_us"] == legs["config5_expand_rollout_65536_pairs"]["us_per_unit"]
+    assert abs(c["config1_us"] - d["ms_per_step"] * 1e3) < 1e-9 and abs(c["config1_frac"] - r["frac"]) < 1e-12
+
+
+def test_expand_out_dicts_with_missing_entries_raise_value_errors():
+    """a dict of expand() handed to expand_rollout() (no value_sum), python_key=True with a dict made without
+    the CPython key, a dict without a child: ValueError like every other bad `out`, never a bare KeyError."""
+    import torch
+    from qtttgym_amd import VecEnv
+    env = VecEnv(256, seed=5)
+    for _ in range(3):
+        env.step_raw(env.sample_actions())
+    act = torch.randint(0, 36, (256,), dtype=torch.uint8, device=env.device)
+    plain = env.expand(act, python_key=False)
+    assert "key" not in plain
+    with pytest.raises(ValueError, match="value_sum"):
+        env.expand_rollout(act, 2, out=plain)
+    with pytest.raises(ValueError, match="'key'"):
+        env.expand(act, out=plain, python_key=True)
+    again = env.expand(act, out=plain)                      # python_key=None: the dict's own choice
+    assert again is plain and "key" not in again
+    xr = env.expand_rollout(act, 2)
+    with pytest.raises(ValueError, match="result"):
+        env.expand_rollout(act, 2, out=xr, with_result=True)
+    broken = dict(plain)
+    del broken["child1"]
+    with pytest.raises(ValueError, match="child1"):
+        env.expand(act, out=broken)
+    fresh = env.expand(act)                                 # a fresh dict carries the CPython key by default
+    assert "key" in fresh and torch.equal(fresh["state_key"], plain["state_key"])
+
+
+_POLL_TIMEOUT_SCRIPT = r"""
+import sys, time
+sys.path.insert(0, %r)
+import torch
+from qtttgym_amd import Board, QEvalClassic, VecEnv
+ref = Board(QEvalClassic())
+ref.make_move((0, 1))
+big = VecEnv(1 << 20, seed=3, auto_reset=True)
+big.step_random_many(64)
+torch.cuda.synchronize()
+b = Board(QEvalClassic())
+t0 = time.perf_counter()
+for _ in range(24):                                     # ~5.5 ms of work on the current stream, not waited for
+    big.step_random_many(64)
+queued = time.perf_counter() - t0
+b.make_move((0, 1))                                     # its launch queues behind them
+waited = time.perf_counter() - t0
+assert queued < 0.004, "the launches were not asynchronous (%%.1f ms): nothing was queued ahead" %% (queued * 1e3)
+assert waited > 0.003, "the record came back before the queued work could have finished (%%.2f ms)" %% (waited * 1e3)
+assert b.moves == ref.moves == [(0, 1, 0)] and b.board == ref.board and b.qstructs == ref.qstructs == [{0, 1}]
+b.make_move((0, 1))                                     # and the facade keeps working afterwards (poll path again)
+assert sorted(b.board[:2]) == [0, 1] and b.qstructs == []
+print("ok")
+"""
+
+
+def _run_script(script, **env):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
+    return out
+
+
+def test_board_op_host_falls_back_to_the_stream_when_the_poll_times_out():
+    """include/qttt.h, qttt_board_op_host on its LAUNCH path (QTTT_BOARD_MAILBOX_US=0): with several ms of kernels queued
+    ahead on the stream the 2 ms poll gives up and the call synchronises the stream instead — same records, stamped."""
+    _run_script(_POLL_TIMEOUT_SCRIPT % ROOT, QTTT_BOARD_MAILBOX_US="0")
+
+
+_MAILBOX_SCRIPT = r"""
+import sys, time, json, random
+sys.path.insert(0, %r)
+import numpy as np
+import torch
+from qtttgym_amd import Board, QEvalClassic, _native
+from qtttgym_amd import board as board_mod
+g = np.load(%r)
+class Bits(QEvalClassic):
+    def __init__(self, bits): self.bits, self.k = bits, 0
+    def choose(self, lo, hi):
+        b = int(self.bits[self.k]); return hi if b else lo
+kinds = list(g["kind"])
+E, T = g["actions"].shape[0], g["actions"].shape[1]
+n_calls = 0
+for e in list(range(0, E, max(1, E // 150)))[:150]:
+    ev = Bits(g["bits"][e]); b = Board(ev)
+    for t in range(T):
+        a = (int(g["actions"][e, t, 0]), int(g["actions"][e, t, 1]))
+        ev.k = t
+        try:
+            b.make_move(a); n_calls += 1
+        except Exception as ex:
+            if isinstance(ex, _native.QtttNativeError): raise
+        assert b.board == [int(x) for x in g["board"][e, t]], (e, t)
+        assert len(b.moves) == int(g["n_moves"][e, t]), (e, t)
+        if e %% 7 == 0 and t %% 3 == 0:
+            time.sleep(0.0006)                       # longer than the idle window: the wave has left, the next call relaunches it
+# a device-wide synchronise right after a call waits for the resident wave at most its idle window (+ slack)
+b = Board(QEvalClassic()); b.make_move((0, 1))
+t0 = time.perf_counter(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+assert dt < 0.005, dt
+print(json.dumps({"calls": n_calls, "sync_after_call_ms": dt * 1e3, "fast": board_mod._stage().fast is not None}))
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("mailbox_us", ["100", "0", "20"])
+def test_board_facade_on_the_golden_episodes_with_and_without_the_mailbox(mailbox_us):
+    """The single-board façade through the bounded mailbox (default window, a short one) and through the launch path:
+    150 golden episodes of the reference, step by step, with pauses longer than the idle window in between (the
+    resident wave leaves and is launched again), and a device-wide synchronise right after a call."""
+    golden = os.path.join(ROOT, "tests", "golden", "step_traces.npz")
+    out = _run_script(_MAILBOX_SCRIPT % (ROOT, golden), QTTT_BOARD_MAILBOX_US=mailbox_us)
+    info = json.loads(out.stdout.strip().splitlines()[-2])
+    assert info["calls"] > 500 and info["fast"] is True           # qtttgym_amd/_fastboard.so is built and in use on the box

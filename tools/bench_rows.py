@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from qtttgym_amd import VecEnv  # noqa: E402
+from qtttgym_amd import recommended_env  # noqa: E402
+recommended_env(apply=True)   # HIP_FORCE_DEV_KERNARG=1 etc., before the first HIP call
 
 
 def timed(fn, reps=20, warm=3, min_s=float(os.environ.get("QTTT_ROWS_MIN_S", "0.02"))):

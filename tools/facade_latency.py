@@ -10,29 +10,37 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from qtttgym_amd import Env, Board, QEvalClassic  # noqa: E402
+from qtttgym_amd import recommended_env  # noqa: E402
+recommended_env(apply=True)   # HIP_FORCE_DEV_KERNARG=1 etc., before the first HIP call
 
 
 def episodes(n_steps):
+    """(seconds per step of the whole loop, seconds per Env.step CALL alone): the loop also pays the random legal move
+    and an Env.reset per episode, which are the harness's, not the environment's"""
     rng = random.Random(3)
     env = Env()
     env.reset()
-    done_steps = 0
+    done_steps, in_step = 0, 0
+    clock = time.perf_counter_ns
     t0 = time.perf_counter()
     while done_steps < n_steps:
         empty = [i for i, v in enumerate(env._gameboard.board) if v == -1]
         if len(empty) < 2:
             env.reset()
             continue
-        _, _, term, _, _ = env.step(tuple(rng.sample(empty, 2)))
+        a = tuple(rng.sample(empty, 2))
+        c0 = clock()
+        _, _, term, _, _ = env.step(a)
+        in_step += clock() - c0
         done_steps += 1
         if term:
             env.reset()
-    return (time.perf_counter() - t0) / done_steps
+    return (time.perf_counter() - t0) / done_steps, in_step * 1e-9 / done_steps
 
 
 def main():
     episodes(200)                                            # warm: library load, pinned buffers, kernels
-    t_env = episodes(3000)
+    t_env_loop, t_env = episodes(3000)
     b = Board(QEvalClassic())
     b.make_move((0, 1))
     n = 3000
@@ -45,6 +53,18 @@ def main():
         b2 = Board(QEvalClassic())
         b2.make_move((i % 8, 8))
     t_mm = (time.perf_counter() - t0) / n
+    # the same mid-game: a board with five moves on it, one more move (copied first, like a search does)
+    mid = Board(QEvalClassic())
+    for mv in ((0, 1), (1, 2), (3, 4), (4, 5), (6, 7)):
+        mid.make_move(mv)
+    t_mid = 0
+    for i in range(n):
+        k = Board(QEvalClassic())
+        k.board, k.moves, k.qstructs = mid.board.copy(), mid.moves.copy(), [set(q) for q in mid.qstructs]
+        c0 = time.perf_counter_ns()
+        k.make_move((2, 8) if i & 1 else (0, 2))             # an entangling move / a cycle (collapse of three squares)
+        t_mid += time.perf_counter_ns() - c0
+    t_mid = t_mid * 1e-9 / n
     # an _expand_child-style loop (mcts.py:210-221): 36 copies of a parent, one move each — one make_move at a
     # time, and as ONE Board.make_moves call
     pairs = [(i, j) for i in range(9) for j in range(i + 1, 9)]
@@ -69,11 +89,15 @@ def main():
     for _ in range(reps):
         Board.make_moves(copies(), pairs)
     t_batch = (time.perf_counter() - t0) / (reps * len(pairs))
-    print(json.dumps({"row": "facade_latency_N1", "Env.step_us": t_env * 1e6, "Board.make_move_us": t_mm * 1e6,
+    from qtttgym_amd import board as board_mod
+    print(json.dumps({"row": "facade_latency_N1", "Env.step_us": t_env * 1e6, "Env.step_loop_us": t_env_loop * 1e6,
+                      "Board.make_move_us": t_mm * 1e6, "Board.make_move_midgame_us": t_mid * 1e6,
+                      "fastboard": board_mod._stage().fast is not None,
+                      "board_mailbox_us": os.environ.get("QTTT_BOARD_MAILBOX_US", "100 (default)"),
                       "expand_36_children_loop_of_make_move_us_per_child": t_loop * 1e6,
                       "expand_36_children_one_make_moves_call_us_per_child": t_batch * 1e6,
                       "Board.check_win_us": t_cw * 1e6, "reference_Env.step_us": 12.0,
-                      "note": "Env.step = one qttt_board_op_host call: a launch + polling the out record's stamp in pinned memory (check_win comes back in the same record); the loop also pays the random legal move and Env.reset of each episode"}))
+                      "note": "Env.step_us = the env.step(action) call alone (perf_counter_ns around it); Env.step_loop_us = the whole random-play loop per step (also the random legal move and an Env.reset per episode: the figure of rounds 3 - 4). One step = one qttt_board_op_host call: a request to the resident mailbox wave (or, QTTT_BOARD_MAILBOX_US=0, a launch + polling the out record's stamp); check_win comes back in the same record"}))
 
 
 if __name__ == "__main__":

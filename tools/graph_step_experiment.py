@@ -8,6 +8,8 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import torch
 from qtttgym_amd import VecEnv
+from qtttgym_amd import recommended_env  # noqa: E402
+recommended_env(apply=True)   # HIP_FORCE_DEV_KERNARG=1 etc., before the first HIP call
 dev = torch.device("cuda", 0)
 for B in (1 << 20, 262144, 4096):
     K, W = 20, 5

@@ -28,6 +28,7 @@ constants / literals) or SLOW (1.75 ns: left shifts, bfe, compares, selects, mul
 SDWA, three-operand or / and-or / lshl-or, anything with an SGPR source).
 
     python tools/isa_budget.py 'step_kernelILi1024ELi2ELb0ELb1ELb0ELb0ELb0E' 2 [measured SQ_INSTS_VALU per board] [-v]
+    python tools/isa_budget.py 'step_random_fused_kernelILi256ELb1ELb0E' 1 138.0 --loop        (the ply loop only)
 
 Arguments: a substring of the kernel's mangled name, boards per lane of that instantiation (counts are divided by
 it), and optionally the measured VALU instructions per board-step (profiles/rNN/pmc_sq_summary.csv): the number of
@@ -89,8 +90,9 @@ def classify(op, enc, args):
 
 
 def main():
-    argv = [a for a in sys.argv[1:] if a != "-v"]
+    argv = [a for a in sys.argv[1:] if a not in ("-v", "--loop")]
     verbose = "-v" in sys.argv
+    loop_only = "--loop" in sys.argv        # count the kernel's LAST depth-1 loop only (the ply loop of the fused kernels)
     pat, bpl = argv[0], int(argv[1])
     measured = float(argv[2]) if len(argv) > 2 else None
     tags = {f: tags_of(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))}
@@ -98,6 +100,15 @@ def main():
     dbg = kernel_body(compile_s(["-gline-tables-only"]), pat)
     if [l.split(";")[0].rstrip() for l in dbg if is_instr(l)] != plain:
         sys.exit("the line-table build's instruction stream differs from the plain build's")
+    if loop_only:
+        labels = [(i, l) for i, l in enumerate(dbg) if re.match(r"^\.LBB\d+_\d+:", l)]
+        head = [l.split(":")[0] for i, l in labels if "Loop Header: Depth=1" in l][-1]                  # ".LBB89_15"
+        tag = "Header=" + head[2:]
+        inside = [k for k, (i, l) in enumerate(labels) if l.startswith(head + ":") or tag in l]
+        first, last = labels[inside[0]][0], (labels[inside[-1] + 1][0] if inside[-1] + 1 < len(labels) else len(dbg))
+        # the location in force at the loop's first instruction is the last .loc in front of it
+        loc = next((l for l in reversed(dbg[:first]) if re.match(r"^\s+\.loc\s", l)), None)
+        dbg = ([loc] if loc else []) + dbg[first:last]
     per = {}            # phase -> [fast, slow, instrs]
     salu = lds = vmem = 0
     cur = "other"

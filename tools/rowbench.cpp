@@ -59,7 +59,7 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused2_kernel(
     int64_t out_stride, int64_t n, int32_t n_steps) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
-    __shared__ uint8_t nth9[512 * 9];
+    __shared__ uint8_t nth9[NTH9_BYTES];
     typedef Vec<u64, 2> V64;
     const int64_t jb = (int64_t)blockIdx.x * BLOCK;                 // first lane-group of the workgroup
     const int64_t j = jb + threadIdx.x;
