@@ -315,6 +315,7 @@ __device__ __forceinline__ void cold_from_attrs(const uint8_t *moves, u32 n_move
 // Valid (reachable) attribute sets give a state whose export is the input again; anything else gives some state
 // without faults or unbounded loops (the walk is bounded by nine nodes).  The single-record Board façade keeps the
 // generic cold_from_attrs path.
+//@isa imp_copy
 template <int BLOCK>
 __device__ inline void tile_copy_in(uint8_t *tile16, const uint8_t *gsrc, u32 nbytes) {
     uint8_t *dst = tile16 + obs_phase(gsrc);
@@ -330,6 +331,7 @@ __device__ inline void wave_copy_in16(uint8_t *tile16, const uint8_t *gsrc, u32 
     if (kb < end) tile16[kb] = gsrc[kb];
 }
 
+//@isa imp_head
 // low nibbles of the four bytes of x -> 16 bits (byte k -> nibble k)
 __device__ __forceinline__ u32 nibbles_of_bytes(u32 x) {
     const u32 y = (x | (x >> 4)) & 0x00FF00FFu;
@@ -371,25 +373,36 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
     const u64 comps_all = (u64)((u32)qm & 0x1FFu) | ((u64)((u32)(qm >> 16) & 0x1FFu) << 9) |
                           ((u64)((u32)(qm >> 32) & 0x1FFu) << 18) | ((u64)((u32)(qm >> 48) & 0x1FFu) << 27);
     const u64 comps = nqc >= 4u ? comps_all : comps_all & ((1ull << (9u * nqc)) - 1ull);
+//@isa imp_moves
     // ---- the rooted forest: insert the un-collapsed moves in round order (the step's own path reversal)
     // The child end is chosen as the step chose it when the move was played (step_child_end4: lo when lo was free of
     // un-collapsed moves, else hi), so that an imported position is bit for bit the state stepping reaches —
     // which is what lets state_key() stand for (board, moves).  "In a component then" = touched by an earlier move
     // that is still un-collapsed now: a component collapses as a whole, so a square whose old component is gone is
     // classical, and so would be every move on it.  (A move of round 8 always closes a cycle: never live.)
+    // WHICH moves are un-collapsed is read off the board once, for all rounds: a move has collapsed iff its round
+    // stands on a square (env.py:72-74 uses the same test), so live = rounds < n_real that are on no square — nine
+    // one-bit shifts instead of two classical-square tests and three range tests per move.  (Attributes no game
+    // reaches give SOME state: a garbage square only ever becomes a shift count, which the hardware reduces, and the
+    // walk is bounded by nine nodes.)
+    u32 on_board = (1u << (b8 & 31u));                                   // (an empty square, -1, sets bit 31: never looked at)
+#pragma unroll
+    for (u32 v = 0; v < 8u; ++v) on_board |= 1u << ((u32)(b07 >> (8u * v)) & 31u);
+    if (is_auto) on_board &= ~(1u << (n_real & 31u));                   // the stripped autofill round is not a move's
+    const u32 live = ~on_board & ((1u << n_real) - 1u) & 0xFFu;
     u64 P = ((u64)W << 2) | ((u64)c8 << 34);
     u32 touched = 0;
 #pragma unroll
     for (u32 t = 0; t < 8u; ++t) {
-        const u32 pr = (u32)((t < 4u ? m03 : m47) >> (16u * (t & 3u))) & 0xFFFFu;
-        const u32 lo = pr & 0xFFu, hi = pr >> 8;
-        if (t < n_real && lo < hi && hi < 9u && ((cl >> lo) & 1u) == 0u && ((cl >> hi) & 1u) == 0u) {
-            const u32 both = (1u << lo) | (1u << hi);
-            const u32 x = ((touched >> lo) & 1u) == 0u ? lo : hi;            // step_child_end4 without a cycle
-            P = step_reroot(P, Q0, x * 4u, t * 4u);                      // x becomes the child end of move t
-            touched |= both;
+        if (live & (1u << t)) {
+            const u32 pr = (u32)((t < 4u ? m03 : m47) >> (16u * (t & 3u)));
+            const u32 lo = pr & 0xFFu, hi = (pr >> 8) & 0xFFu;
+            const u32 x = ((touched >> (lo & 31u)) & 1u) == 0u ? lo : hi;    // step_child_end4 without a cycle
+            P = step_reroot(P, Q0, (x * 4u) & 63u, t * 4u);                  // x becomes the child end of move t
+            touched |= (1u << (lo & 31u)) | (1u << (hi & 31u));
         }
     }
+//@isa imp_tail
     u32 P0 = (u32)P, P1 = (u32)(P >> 32) & 0x3Fu;
     P1 |= (n_real << P1_N_SHIFT) | (((u32)(comps >> 32) & 0xFu) << P1_CHI_SHIFT) | (last_x << P1_LX_SHIFT) | (cl << P1_CL_SHIFT);
     step_line(P0, P1, lut);                                              // done = a completed line or nine moves (env.py:51)
@@ -397,6 +410,7 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
     Qout = (u64)Q0 | ((u64)(u32)comps << 32);
 }
 
+//@isa imp_copy
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void import_kernel(u64 *pP, u64 *pQ, ExpOut in, int64_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[exp_lds_bytes(BLOCK)];
@@ -411,7 +425,26 @@ __global__ __launch_bounds__(BLOCK) void import_kernel(u64 *pP, u64 *pQ, ExpOut 
     fill_line_lut_nosync<BLOCK>(lut);
     if ((all & 15u) == 0u) {                                             // every wave fetches the rows it will read
         const u32 w0 = threadIdx.x & ~63u, w1 = min(w0 + 64u, valid);
-        if (w0 < valid) {
+        if (w1 == w0 + 64u) {
+            // a full wave: 64 rows = 72 + 36 + 32 + 4 + 4 sixteen-byte pieces.  ALL six loads are requested before the
+            // first one is waited for (the generic loop below waits for each piece before it asks for the next: six
+            // memory round trips in a row per wave — 20.9 us per 1 M boards against 9 for the export, round 4)
+            const u32 lane = threadIdx.x & 63u;
+            const u32x4 *q_mv = reinterpret_cast<const u32x4 *>(g_mv + w0 * 18u), *q_bd = reinterpret_cast<const u32x4 *>(g_bd + w0 * 9u);
+            const u32x4 *q_qm = reinterpret_cast<const u32x4 *>(g_qm + w0 * 8u), *q_nm = reinterpret_cast<const u32x4 *>(g_nm + w0);
+            const u32x4 *q_nq = reinterpret_cast<const u32x4 *>(g_nq + w0);
+            u32x4 a0, a1, b0, c0, d0, e0;
+            a0 = __builtin_nontemporal_load(&q_mv[lane]);
+            if (lane < 8u) a1 = __builtin_nontemporal_load(&q_mv[64u + lane]);
+            if (lane < 36u) b0 = __builtin_nontemporal_load(&q_bd[lane]);
+            if (lane < 32u) c0 = __builtin_nontemporal_load(&q_qm[lane]);
+            if (lane < 4u) { d0 = __builtin_nontemporal_load(&q_nm[lane]); e0 = __builtin_nontemporal_load(&q_nq[lane]); }
+            reinterpret_cast<u32x4 *>(l_mv + w0 * 18u)[lane] = a0;
+            if (lane < 8u) reinterpret_cast<u32x4 *>(l_mv + w0 * 18u)[64u + lane] = a1;
+            if (lane < 36u) reinterpret_cast<u32x4 *>(l_bd + w0 * 9u)[lane] = b0;
+            if (lane < 32u) reinterpret_cast<u32x4 *>(l_qm + w0 * 8u)[lane] = c0;
+            if (lane < 4u) { reinterpret_cast<u32x4 *>(l_nm + w0)[lane] = d0; reinterpret_cast<u32x4 *>(l_nq + w0)[lane] = e0; }
+        } else if (w0 < valid) {
             wave_copy_in16(l_mv, g_mv, w0 * 18u, w1 * 18u);
             wave_copy_in16(l_bd, g_bd, w0 * 9u, w1 * 9u);
             wave_copy_in16(l_qm, g_qm, w0 * 8u, w1 * 8u);
@@ -443,6 +476,7 @@ __global__ __launch_bounds__(BLOCK) void import_kernel(u64 *pP, u64 *pQ, ExpOut 
 }
 
 // Board.make_move / update_qstructs / check_win (board.py:9-115) on caller-assigned attributes, one
+//@isa other
 // 64-byte record in, one out (include/qttt.h: qttt_board_op): import -> the SAME step_core the
 // batch kernels run -> export + check_win, in one launch, so that the single-board façade costs one
 // round trip.  The records may live in pinned host memory (the kernel reads and writes them

@@ -163,7 +163,7 @@ def main():
     print("per board-step; further walk nodes executed per wave: %.2f%s" % (iters, " (solved from the measured %.1f)" % measured if measured else " (assumed)"))
     print("%-9s %7s %6s %6s %8s" % ("phase", "VALU", "fast", "slow", "issue ns"))
     tot = tf = ts = 0.0
-    for ph in ORDER:
+    for ph in ORDER + sorted(k for k in per if k not in ORDER):
         if ph not in per:
             continue
         f, s = per[ph][0], per[ph][1]
@@ -178,7 +178,7 @@ def main():
     print("%-9s %7.1f %6.1f %6.1f %8.1f" % ("total", tot, tf, ts, tf * T_FAST + ts * T_SLOW))
     print("(one further node = %.1f VALU: %.1f fast + %.1f slow)" % (per_node, per_node_f, per_node_s))
     if verbose:
-        for ph in ORDER:
+        for ph in ORDER + sorted(k for k in per if k not in ORDER):
             if ph in per:
                 print("\n[%s]" % ph)
                 seen = per[ph][2]
