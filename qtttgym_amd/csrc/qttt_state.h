@@ -64,7 +64,11 @@ template <> struct RawOf<32> { typedef u32x8 type; };
 template <typename V>
 __device__ __forceinline__ V load_stream(const V *p) {
     typedef typename RawOf<sizeof(V)>::type R;
+#ifdef QTTT_PLAIN_LOADS                       // (A/B builds only: the loads without the non-temporal hint)
+    R r = *reinterpret_cast<const R *>(p);
+#else
     R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+#endif
     V v;
     __builtin_memcpy(&v, &r, sizeof(V));
     return v;
@@ -75,6 +79,34 @@ __device__ __forceinline__ void store_stream(V *p, const V &v) {
     R r;
     __builtin_memcpy(&r, &v, sizeof(V));
     __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+}
+
+// The same store through a block-uniform base in scalar registers + a 32-bit lane offset (the addressing the loads get
+// by themselves): written out, because for these stores the compiler builds per-lane 64-bit addresses instead
+// (two v_lshl_add_u64 per lane in the step kernel).  8-, 16- and 32-byte vectors.
+template <typename V>
+__device__ __forceinline__ void store_stream_sbase(void *block_base, u32 byte_offset, const V &v) {
+    static_assert(sizeof(V) == 8 || sizeof(V) == 16 || sizeof(V) == 32, "plane vectors only");
+#ifdef QTTT_NO_SBASE_STORES                    // (A/B builds only: the compiler's own addressing)
+    store_stream(reinterpret_cast<V *>(static_cast<uint8_t *>(block_base) + byte_offset), v);
+    return;
+#endif
+    if constexpr (sizeof(V) == 8) {
+        u32x2 r;
+        __builtin_memcpy(&r, &v, 8);
+        asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(byte_offset), "v"(r), "s"(block_base) : "memory");
+    } else if constexpr (sizeof(V) == 16) {
+        u32x4 r;
+        __builtin_memcpy(&r, &v, 16);
+        // (s_nop: a store of more than 64 bits followed by a VALU write of its data registers needs one wait state;
+        // the compiler inserts it for its own stores, it cannot see into this one)
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(byte_offset), "v"(r), "s"(block_base) : "memory");
+    } else {
+        u32x4 r[2];
+        __builtin_memcpy(r, &v, 32);
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(byte_offset), "v"(r[0]), "s"(block_base) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 offset:16 nt\n\ts_nop 0" : : "v"(byte_offset), "v"(r[1]), "s"(block_base) : "memory");
+    }
 }
 
 __device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
@@ -109,9 +141,40 @@ __device__ __forceinline__ u32 line_lut_entry(u32 m) {
     const bool diag = (m & 0x111u) == 0x111u || (m & 0x054u) == 0x054u;
     return ((rows | cols) != 0u || diag) ? 0x7Fu : 0u;
 }
+// The same 512 answers as one bit each (bit m of the 512-bit word: mask m contains a line).  A wave covers 64
+// consecutive masks = one 64-bit piece, fetched with a SCALAR load (its own counter: nothing of the wave's vector loads is
+// waited for) — a shift, an AND and a multiply per table entry instead of the twenty instructions of line_lut_entry().
+struct LineBits {
+    u64 w[8];
+    constexpr LineBits() : w() {
+        for (u32 m = 0; m < 512u; ++m) {
+            const u32 rows = m & (m >> 1) & (m >> 2) & 0x049u, cols = m & (m >> 3) & (m >> 6) & 0x007u;
+            const bool diag = (m & 0x111u) == 0x111u || (m & 0x054u) == 0x054u;
+            if ((rows | cols) != 0u || diag) w[m >> 6] |= 1ull << (m & 63u);
+        }
+    }
+};
+__constant__ LineBits g_line_bits = LineBits();
 template <int BLOCK>
 __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
-    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) reinterpret_cast<u32 *>(lut)[w] = line_lut_entry(w);
+    static_assert(BLOCK % 64 == 0, "a wave covers one 64-bit piece of the table");
+    // From 512 threads up (one entry per thread at most) the scalar piece; in 256-thread workgroups — the launch shape of
+    // the latency-bound batches, where the scalar load's own latency sits in front of the barrier — the entry is computed
+    // (tools/stepbench, 262 144 boards: 3.52 against 3.74 us best, 3.83 / 3.89 median; 1 M boards, policy in the step
+    // kernel: 7.31 with the scalar piece against 7.50 computed).
+#ifdef QTTT_LUT_COMPUTED                       // (A/B builds only: always computed, as up to round 4)
+    constexpr bool SCALAR_PIECE = false;
+#else
+    constexpr bool SCALAR_PIECE = BLOCK >= 512;
+#endif
+    for (u32 w = threadIdx.x; w < 512u; w += BLOCK) {
+        if constexpr (SCALAR_PIECE) {
+            const u64 piece = g_line_bits.w[__builtin_amdgcn_readfirstlane(w >> 6)];  // wave-uniform: s_load_dwordx2
+            reinterpret_cast<u32 *>(lut)[w] = ((u32)(piece >> (w & 63u)) & 1u) * 0x7Fu;
+        } else {
+            reinterpret_cast<u32 *>(lut)[w] = line_lut_entry(w);
+        }
+    }
 }
 template <int BLOCK>
 __device__ inline void fill_line_lut(uint8_t *lut) {

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
             tm.v[k] = (uint8_t)(P1 >> 31);
             if (OBS) obs_board(P0, P1, Q0, T, g * BPL + (u32)k, olut);
         }
-        store_stream(&reinterpret_cast<V64 *>(pP + ib)[g], p);
-        store_stream(&reinterpret_cast<V64 *>(pQ + ib)[g], q);
+        store_stream_sbase(pP + ib, g * (u32)sizeof(V64), p);          // block-uniform base + 32-bit lane offset, like the loads
+        store_stream_sbase(pQ + ib, g * (u32)sizeof(V64), q);
         if (SAMPLE && actions) store_stream(&reinterpret_cast<V16 *>(actions + ib)[g], act);
         store_stream(&reinterpret_cast<V32 *>(reward_bits + ib)[g], rw);
         store_stream(&reinterpret_cast<V8 *>(terminated + ib)[g], tm);

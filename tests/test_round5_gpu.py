@@ -10,9 +10,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# The GPU boxes of this pool allow at most 6 processes on a card at once: the driver-shaped N = 8 command is rehearsed
-# with 6 ranks here; its eight-rank bookkeeping runs on CPU gloo ranks in tests/test_round5_cpu.py.
-RANKS_ON_ONE_CARD = 6
+# The GPU boxes of this pool allow at most 6 processes on a card at once, and the pytest process itself is one of them
+# once an earlier test has touched the GPU: the driver-shaped N = 8 command is rehearsed with 4 ranks here (4 + pytest
+# = 5); its eight-rank bookkeeping runs on CPU gloo ranks in tests/test_round5_cpu.py.
+RANKS_ON_ONE_CARD = 4
 
 
 def bench(*args, env=None, check=True):
@@ -30,8 +31,8 @@ def bench(*args, env=None, check=True):
 
 
 @pytest.mark.timeout(900)
-def test_driver_shape_with_six_gloo_ranks_on_the_one_card():
-    """`python bench.py --gpus N --steps 20 --warmup 5` as the driver runs it (self-launched ranks, no torchrun), N = 6
+def test_driver_shape_with_four_gloo_ranks_on_the_one_card():
+    """`python bench.py --gpus N --steps 20 --warmup 5` as the driver runs it (self-launched ranks, no torchrun), N = 4
     ranks sharing the one GPU over gloo: every rank is in the line, in rank order."""
     n = RANKS_ON_ONE_CARD
     out, lines = bench("--gpus", str(n), "--steps", "20", "--warmup", "5", "--boards", "131072",
