@@ -39,7 +39,7 @@ Commands.  The headline (and what the driver's SCALE run measures, WEAK scaling:
 GPUs are N independent loops and the >= 7x of BASELINE.json holds by construction):
     python bench.py --gpus N --steps K --warmup W
 BASELINE config 4 as stated (2 097 152 boards over 8 GPUs, STRONG scaling: 262 144 boards per GPU is one partial
-occupancy round per launch, predicted 3.4 - 4.1x launch-per-step and 5.8 - 6.4x fused, DESIGN.md §8 — the >= 7x claim
+occupancy round per launch, predicted 3.9 - 4.1x launch-per-step and 5.4 - 5.7x fused, DESIGN.md §8 — the >= 7x claim
 does NOT apply to it):
     python bench.py --gpus 8 --total-boards 2097152 --mode random-fused
 QTTT_BENCH_NO_GATHER=1 skips the optional returns gather (the only collective that moves per-board data).
