@@ -433,11 +433,11 @@ def run_legs(torch, dev, args):
             # VALU-bound (the boards never leave the registers): SQ_INSTS_VALU per board-step (a committed PMC
             # figure, not measured in this run) against the chip's best wave-instruction issue rate
             leg.update(bound="valu", steps_per_launch=min(fused_T, K), us_per_launch=us * min(fused_T, K),
-                       valu_insts_per_board_step=FUSED_VALU_PER_STEP, valu_source="profiles/r04/pmc_sq_fused_summary.csv",
+                       valu_insts_per_board_step=FUSED_VALU_PER_STEP, valu_source="profiles/r05/pmc_sq_fused_summary.csv",
                        valu_peak_ginst_per_s=VALU_PEAK_GINST,
                        valu_frac=None if FUSED_VALU_PER_STEP is None else
                        FUSED_VALU_PER_STEP * (B / 64.0) / (ev / K * 1e9) / VALU_PEAK_GINST,
-                       issue_ns_per_wave_ply=FUSED_ISSUE_NS_PER_WAVE_PLY, issue_source="tools/isa_mix.py",
+                       issue_ns_per_wave_ply=FUSED_ISSUE_NS_PER_WAVE_PLY, issue_source="tools/isa_budget.py --loop",
                        issue_frac=FUSED_ISSUE_NS_PER_WAVE_PLY * (B / 64.0 / 1024.0) / (ev / K * 1e9))
         else:
             leg["us_per_launch"] = us
@@ -502,13 +502,15 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
     return out
 
 
-# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 155 497 902 per dispatch of 1 048 576 boards x
-# 64 steps = 9 490.8 per wave = 148.3 per ply (profiles/r04/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass)
-FUSED_VALU_PER_STEP = 148.3
-# issue time of that instruction mix per wave and ply (tools/isa_mix.py: 57 % of the 148.3 in the slow class, 1.75 ns
-# per instruction per SIMD, the rest at 1.03 ns — a literal operand does not make a logic instruction slow, an SGPR
-# operand does: profiles/r02/valu_rates.txt): what a SIMD needs per resident wave and ply when it never idles
-FUSED_ISSUE_NS_PER_WAVE_PLY = 213.7
+# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 141 635 277 per dispatch of 1 048 576 boards x
+# 64 steps = 8 644.7 per wave = 135.1 per ply (profiles/r05/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass;
+# round 4: 148.3)
+FUSED_VALU_PER_STEP = 135.1
+# issue time of that instruction mix per wave and ply (tools/isa_budget.py --loop, profiles/r05/isa_budget_random_fused.txt:
+# 65.0 of the 135.1 in the fast class at 1.03 ns per instruction per SIMD, 70.1 in the slow class at 1.75 — a literal
+# operand does not make a logic instruction slow, an SGPR operand does: profiles/r02/valu_rates.txt): what a SIMD needs
+# per resident wave and ply when it never idles
+FUSED_ISSUE_NS_PER_WAVE_PLY = 189.6
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):

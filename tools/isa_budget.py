@@ -177,6 +177,10 @@ def main():
         tot += f + s; tf += f; ts += s
     print("%-9s %7.1f %6.1f %6.1f %8.1f" % ("total", tot, tf, ts, tf * T_FAST + ts * T_SLOW))
     print("(one further node = %.1f VALU: %.1f fast + %.1f slow)" % (per_node, per_node_f, per_node_s))
+    if measured and "table" in per and not loop_only:
+        print("(the counts are static: a phase only SOME waves of a workgroup execute — the line table's entries, threads < 512 —\n"
+              " is counted in full, so the number of further nodes solved from the measured total is a lower bound; the fused kernel's\n"
+              " ply loop, where every wave runs everything, solves to the walk's true 64-lane maximum)")
     if verbose:
         for ph in ORDER + sorted(k for k in per if k not in ORDER):
             if ph in per:
