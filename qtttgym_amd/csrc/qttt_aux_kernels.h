@@ -355,11 +355,11 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
             (nibbles_of_bytes(~bhi & 0x0F0F0F0Fu & ((chi << 8) - chi)) << 16);
     u32 c8 = (b8 & 0x80u) ? 0u : (~b8 & 0xFu);
     // ---- Board.moves: x nibbles; the last move (an explicit autofill move is stripped: board.py:22-25 is implicit here)
-    const u32 last = n - 1u;                                             // (n == 0: nothing below looks at it)
-    const u32 pair = last >= 8u ? m8 : (u32)((last < 4u ? m03 : m47) >> (16u * (last & 3u))) & 0xFFFFu;
-    const u32 l_lo = pair & 0xFFu, l_hi = (pair >> 8) & 0xFFu;
-    const bool is_auto = n >= 1u && l_lo == l_hi && l_lo < 9u;
-    const u32 n_real = is_auto ? n - 1u : n;
+    // the autofill move is (idx, idx, 8), always of round 8 (eight squares must have collapsed first: SURVEY.md §8a), so
+    // it can only be the ninth entry
+    const u32 l_lo = m8 & 0xFFu, l_hi = (m8 >> 8) & 0xFFu;
+    const bool is_auto = n == 9u && l_lo == l_hi && l_lo < 9u;
+    const u32 n_real = is_auto ? 8u : n;
     if (is_auto) {
         cl &= ~(1u << l_lo);
         if (l_lo < 8u) W &= ~(0xFu << (4u * l_lo)); else c8 = 0u;
@@ -396,10 +396,10 @@ __device__ __forceinline__ void import_board(u64 m03, u64 m47, u32 m8, u32 nmv, 
     for (u32 t = 0; t < 8u; ++t) {
         if (live & (1u << t)) {
             const u32 pr = (u32)((t < 4u ? m03 : m47) >> (16u * (t & 3u)));
-            const u32 lo = pr & 0xFFu, hi = (pr >> 8) & 0xFFu;
-            const u32 x = ((touched >> (lo & 31u)) & 1u) == 0u ? lo : hi;    // step_child_end4 without a cycle
-            P = step_reroot(P, Q0, (x * 4u) & 63u, t * 4u);                  // x becomes the child end of move t
-            touched |= (1u << (lo & 31u)) | (1u << (hi & 31u));
+            const u32 lo = pr & 0xFu, hi = (pr >> 8) & 0xFu;                 // (squares are 0..8; four bits keep every shift below defined)
+            const u32 x = ((touched >> lo) & 1u) == 0u ? lo : hi;            // step_child_end4 without a cycle
+            P = step_reroot(P, Q0, x * 4u, t * 4u);                          // x becomes the child end of move t
+            touched |= (1u << lo) | (1u << hi);
         }
     }
 //@isa imp_tail
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(BLOCK) void import_kernel(u64 *pP, u64 *pQ, ExpOut 
     uint8_t *l_mv = tile, *l_bd = l_mv + obs_tile_bytes(BLOCK, 18), *l_qm = l_bd + obs_tile_bytes(BLOCK, 9);
     uint8_t *l_nm = l_qm + obs_tile_bytes(BLOCK, 8), *l_nq = l_nm + obs_tile_bytes(BLOCK, 1);
     const uintptr_t all = (uintptr_t)g_mv | (uintptr_t)g_bd | (uintptr_t)g_qm | (uintptr_t)g_nm | (uintptr_t)g_nq;
-    fill_line_lut_nosync<BLOCK>(lut);
+    fill_line_lut_nosync<BLOCK, 1>(lut);
     if ((all & 15u) == 0u) {                                             // every wave fetches the rows it will read
         const u32 w0 = threadIdx.x & ~63u, w1 = min(w0 + 64u, valid);
         if (w1 == w0 + 64u) {

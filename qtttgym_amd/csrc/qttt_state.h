@@ -155,7 +155,8 @@ struct LineBits {
     }
 };
 __constant__ LineBits g_line_bits = LineBits();
-template <int BLOCK>
+// SCALAR: 1 = always the scalar piece (kernels that are not launch-latency-bound at any size, e.g. import), -1 = by BLOCK
+template <int BLOCK, int SCALAR = -1>
 __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
     static_assert(BLOCK % 64 == 0, "a wave covers one 64-bit piece of the table");
     // From 512 threads up (one entry per thread at most) the scalar piece; in 256-thread workgroups — the launch shape of
@@ -165,7 +166,7 @@ __device__ inline void fill_line_lut_nosync(uint8_t *lut) {
 #ifdef QTTT_LUT_COMPUTED                       // (A/B builds only: always computed, as up to round 4)
     constexpr bool SCALAR_PIECE = false;
 #else
-    constexpr bool SCALAR_PIECE = BLOCK >= 512;
+    constexpr bool SCALAR_PIECE = SCALAR == 1 || BLOCK >= 512;
 #endif
     for (u32 w = threadIdx.x; w < 512u; w += BLOCK) {
         if constexpr (SCALAR_PIECE) {
