@@ -562,18 +562,18 @@ def config5_leg(torch, dev, args, n=65536, K=50):
 CPU_AFFINITY = None
 
 
-def bind_cpu(args):
-    """Bind this rank to the cores local to its GPU (sysfs only: nothing here touches HIP).  QTTT_BENCH_NO_BIND=1 skips it.
-    The result goes into config.cpu_affinity."""
+def bind_cpu(n_dev):
+    """Bind this rank to the cores local to its GPU (sysfs + sched_setaffinity only: nothing here touches HIP; n_dev comes
+    from torch.cuda.device_count(), which does not initialise the GPU).  QTTT_BENCH_NO_BIND=1 skips it.  The result goes
+    into config.cpu_affinity."""
     global CPU_AFFINITY
     from qtttgym_amd.affinity import bind_to_gpu
     if os.environ.get("QTTT_BENCH_NO_BIND") == "1":
         CPU_AFFINITY = {"bound": False, "reason": "QTTT_BENCH_NO_BIND=1"}
         return
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # several gloo ranks rehearsing on one card all map to device local_rank % n_dev; without HIP the device count is not
-    # known here, so an index past the topology simply reports "not found" and binds nothing
-    CPU_AFFINITY = bind_to_gpu(local_rank)
+    # (several gloo ranks rehearsing on one card all use device local_rank % n_dev)
+    CPU_AFFINITY = bind_to_gpu(local_rank % max(n_dev, 1), expected_devices=n_dev)
 
 
 def run(args):
@@ -587,12 +587,13 @@ def run(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    affinity = CPU_AFFINITY          # made in main(), before torch was imported
     # one rank per GPU; QTTT_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (plumbing only)
     backend = os.environ.get("QTTT_DIST_BACKEND", "nccl")
     n_dev = torch.cuda.device_count()
     if n_dev < 1:
         raise SystemExit("no HIP device visible; bench.py has no CPU path")
+    bind_cpu(n_dev)                  # before anything initialises HIP (device_count() does not)
+    affinity = CPU_AFFINITY
     if backend == "nccl" and world > n_dev:
         raise SystemExit("--gpus %d needs %d GPUs, %d visible (QTTT_DIST_BACKEND=gloo rehearses several "
                          "ranks on one GPU)" % (world, world, n_dev))
@@ -640,6 +641,13 @@ def run(args):
         B, offset, total = hi - lo, lo, args.total_boards
     else:
         B, offset, total = args.boards, rank * args.boards, args.boards * world
+    # Everything of this run is enqueued on ONE created stream, made the current one (the library launches on the caller's
+    # current stream; the HIP events of the clock are recorded on it): the legacy default stream costs 0.1 us per launch
+    # more at K = 20 (7.21 - 7.24 against 7.07 - 7.12 us, 7.05 - 7.23 against 7.00 - 7.16 at K = 1000; same box, alternating,
+    # profiles/r05/bench_stream_ab.txt).  QTTT_BENCH_DEFAULT_STREAM=1 keeps the default stream.
+    own_stream = os.environ.get("QTTT_BENCH_DEFAULT_STREAM") != "1"
+    if own_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     wl = Workload(torch, dev, B, K, W, args.seed, offset, args.mode, args.fused_steps)
     env, state_bytes, algo_bytes = wl.env, wl.state_bytes, wl.algo_bytes
     ev_med, ev_min, wall_med, R = wl.measure(barrier, all_max, regions=args.regions)
@@ -742,6 +750,7 @@ def run(args):
                            "dist_backend": backend if use_dist else None,
                            "self_launched": bool(os.environ.get("QTTT_BENCH_SELF_LAUNCHED")),
                            "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                           "stream": "created, current" if own_stream else "legacy default",
                            "cpu_affinity": affinity,                      # rank 0's (every rank binds to its own GPU's cores)
                            "board_offset_last_rank": shard_range(total, world - 1, world)[0] if strong else (world - 1) * B,
                            "replay_matches_recording": replay_ok,
@@ -830,7 +839,6 @@ def main():
         raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1, --total-boards >= --gpus")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # before anything imports torch or touches the GPU
-    bind_cpu(args)                           # likewise: sysfs + sched_setaffinity only
     sys.exit(run(args))
 
 

@@ -76,15 +76,40 @@ def visible_index(local_index, environ=None):
     return idx
 
 
-def bind_to_gpu(local_index, kfd_root=KFD_NODES, pci_root=PCI_DEVICES, apply=True):
+def visible_count(n_kfd, environ=None):
+    """how many devices HIP should enumerate given n_kfd GPUs in the topology and the *_VISIBLE_DEVICES lists (None if a
+    list is not plain integers)"""
+    environ = os.environ if environ is None else environ
+    n = n_kfd
+    for var in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):       # outer -> inner
+        v = environ.get(var)
+        if v is None or v.strip() == "":
+            continue
+        try:
+            ids = [int(x) for x in v.split(",")]
+        except ValueError:
+            return None
+        n = len([i for i in ids if 0 <= i < n])
+    return n
+
+
+def bind_to_gpu(local_index, kfd_root=KFD_NODES, pci_root=PCI_DEVICES, apply=True, expected_devices=None):
     """Restrict this process to the cores local to HIP device `local_index`.  Returns a small dict for the bench line:
-    {'bound': bool, 'numa_node': int | None, 'cpus': n, 'cpulist': '...', 'reason': why not}.  Never raises."""
+    {'bound': bool, 'numa_node': int | None, 'cpus': n, 'cpulist': '...', 'reason': why not}.  Never raises.
+    expected_devices: the number of devices HIP enumerates (torch.cuda.device_count(), which does not initialise the GPU):
+    if the topology (through the *_VISIBLE_DEVICES lists) does not account for exactly that many — a container that hides
+    GPUs by other means — the index -> PCI address mapping is not known and nothing is bound."""
     info = {"bound": False, "numa_node": None, "cpus": None, "cpulist": None, "reason": None}
     try:
         allowed = os.sched_getaffinity(0)
         info["cpus"], info["cpulist"] = len(allowed), format_cpulist(allowed)
         k = visible_index(int(local_index))
         gpus = kfd_gpus(kfd_root)
+        if expected_devices is not None and visible_count(len(gpus)) != int(expected_devices):
+            info["reason"] = ("the topology lists %d GPUs (%s through the *_VISIBLE_DEVICES lists), HIP enumerates %d: "
+                              "which PCI device is device %s is not known" % (len(gpus), visible_count(len(gpus)),
+                                                                              int(expected_devices), local_index))
+            return info
         if k is None or k >= len(gpus):
             info["reason"] = "device %s not found in the KFD topology (%d GPUs)" % (local_index, len(gpus))
             return info

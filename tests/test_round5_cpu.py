@@ -64,6 +64,14 @@ def test_affinity_helper_on_a_made_up_topology(tmp_path, monkeypatch):
     assert c["bound"] is False and "not found" in c["reason"]
     d = affinity.bind_to_gpu(0, str(tmp_path / "nowhere"), pci)         # unreadable: nothing bound, no exception
     assert d["bound"] is False and d["reason"]
+    # a container that hides GPUs by other means than the *_VISIBLE_DEVICES lists: the topology shows two, HIP sees one —
+    # which one is not known, nothing is bound
+    e = affinity.bind_to_gpu(0, kfd, pci, apply=False, expected_devices=1)
+    assert e["bound"] is False and e["numa_node"] is None and "not known" in e["reason"]
+    assert affinity.bind_to_gpu(0, kfd, pci, apply=False, expected_devices=2)["numa_node"] == 0
+    assert affinity.visible_count(8, {}) == 8 and affinity.visible_count(8, {"HIP_VISIBLE_DEVICES": "3"}) == 1
+    assert affinity.visible_count(8, {"ROCR_VISIBLE_DEVICES": "0,1,2,3", "HIP_VISIBLE_DEVICES": "1,0"}) == 2
+    assert affinity.visible_count(8, {"HIP_VISIBLE_DEVICES": "GPU-1234"}) is None
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")                    # HIP device 0 is KFD GPU 1
     assert affinity.visible_index(0) == 1 and affinity.bind_to_gpu(0, kfd, pci, apply=False)["numa_node"] == 1
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")             # a UUID list is not resolved

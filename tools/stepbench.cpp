@@ -305,6 +305,11 @@ int main(int argc, char **argv) {
     for (auto &L : libs) {
         const int64_t sb_per_board = L.state_bytes(64) / 64;      // 16 or 20, by build
         const double lib_bytes = (2.0 * sb_per_board + 7.0) * n;  // algorithmic bytes of the library's layout
+        if (getenv("STEPBENCH_ALL")) {                              // every rep in time order (is the spread a drift or spikes?)
+            printf("reps  %-44s", L.spec.c_str());
+            for (float v : L.us) printf(" %.2f", v);
+            printf("\n");
+        }
         std::sort(L.us.begin(), L.us.end());
         printf("step  %-44s us/launch min %6.2f med %6.2f  %6.1f Gsteps/s %5.0f GB/s (%d B state)\n", L.spec.c_str(), L.us.front(),
                L.us[L.us.size() / 2], n / L.us.front() * 1e-3, lib_bytes / L.us.front() * 1e-3, (int)sb_per_board);
