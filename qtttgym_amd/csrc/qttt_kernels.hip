@@ -157,13 +157,30 @@ uint64_t qttt_hash(uint64_t seed, uint64_t board_id, uint32_t step_idx) {
     return ((u64)h2 << 32) | h1;
 }
 
+}  // extern "C"
+namespace {
+// the empty board is the all-zero state: 16 bytes of zeros per lane, with the step kernel's own
+// non-temporal stores
+__global__ __launch_bounds__(256) void reset_kernel(u32x4 *state, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(u32x4{0u, 0u, 0u, 0u}, &state[i]);
+}
+}  // namespace
+extern "C" {
+
 int qttt_reset(void *state, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
     if (!state) return QTTT_ERR_NULL;
-    // the empty board is the all-zero state
+#ifdef QTTT_RESET_MEMSET                      // (A/B builds only: hipMemsetAsync, as up to round 4)
     hipError_t e = hipMemsetAsync(state, 0, (size_t)(plane_stride(n) * QTTT_STATE_BYTES), (hipStream_t)stream);
     return e == hipSuccess ? 0 : (int)e;
+#else
+    const int64_t n16 = plane_stride(n) * QTTT_STATE_BYTES / 16;
+    hipLaunchKernelGGL(reset_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<u32x4 *>(state), n16);
+    return launch_status();
+#endif
 }
 
 static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint64_t seed,
