@@ -600,6 +600,17 @@ def run(args):
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if not affinity.get("bound") and os.environ.get("QTTT_BENCH_NO_BIND") != "1":
+        # the topology was not readable before the runtime came up (the containers of this pool): ask the runtime for
+        # the device's PCI address now and bind the launching thread to that device's cores
+        try:
+            from qtttgym_amd.affinity import bind_to_pci
+            pr = torch.cuda.get_device_properties(dev)
+            first = affinity.get("reason")
+            affinity = bind_to_pci("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+            affinity["before_runtime"] = first
+        except Exception as e:                                   # noqa: BLE001 — never take the run down
+            affinity = dict(affinity, pci_error="%s: %s" % (type(e).__name__, e))
     # QTTT_DIST_FORCE=1: build the process group and run every collective of the N > 1 path with one
     # rank too (a one-GPU box can then exercise the RCCL branch; tests/test_bench_contract_gpu.py)
     use_dist = world > 1 or os.environ.get("QTTT_DIST_FORCE") == "1"

@@ -6,6 +6,12 @@ No torch, no HIP: everything is read from sysfs, so it can run before anything i
 /sys/class/kfd/kfd/topology/nodes/*/properties (the order HIP enumerates the GPUs in, before *_VISIBLE_DEVICES) gives each
 GPU's PCI address, /sys/bus/pci/devices/<address>/{numa_node,local_cpulist} the cores next to it.  Anything unreadable,
 a node of -1 with no narrower core list, or a core list outside the process's allowed set = do nothing and say so.
+Where the KFD topology is not readable (the containers of this pool: PermissionError) bind_to_pci() does the same from the
+device's own PCI address, which the caller gets from the runtime once it is up (hipDeviceGetPCIBusId /
+torch.cuda.get_device_properties): what matters is where the LAUNCHING thread runs, and that can be set at any time.
+On the pool's two-socket hosts (256 CPUs, four GPUs per socket) the binding itself works (128 cores of the GPU's node); it
+did NOT remove the run-to-run spread of launch-bound batches there (262 144 boards: 3.4 - 4.7 us per launch bound and unbound
+alike, profiles/r05/bench_socket_binding_ab.txt) — it is kept for the 8-rank case, where eight unpinned Python loops share a host.
 """
 import os
 
@@ -91,6 +97,33 @@ def visible_count(n_kfd, environ=None):
             return None
         n = len([i for i in ids if 0 <= i < n])
     return n
+
+
+def bind_to_pci(address, pci_root=PCI_DEVICES, apply=True):
+    """Restrict this process to the cores local to the PCI device `address` ('0000:72:00.0').  Same result dict as
+    bind_to_gpu, 'via': 'pci'.  Never raises."""
+    info = {"bound": False, "numa_node": None, "cpus": None, "cpulist": None, "reason": None, "via": "pci", "device": address}
+    try:
+        allowed = os.sched_getaffinity(0)
+        info["cpus"], info["cpulist"] = len(allowed), format_cpulist(allowed)
+        dev = os.path.join(pci_root, address)
+        with open(os.path.join(dev, "numa_node")) as f:
+            info["numa_node"] = int(f.read().strip())
+        with open(os.path.join(dev, "local_cpulist")) as f:
+            local = parse_cpulist(f.read())
+        want = local & allowed
+        if not want:
+            info["reason"] = "the GPU's local cores are outside this process's allowed set"
+        elif want == allowed:
+            info["reason"] = "the allowed set is already the GPU's local cores"
+        elif apply:
+            os.sched_setaffinity(0, want)
+            info.update(bound=True, cpus=len(want), cpulist=format_cpulist(want))
+        else:
+            info.update(cpus=len(want), cpulist=format_cpulist(want), reason="apply=False")
+    except (OSError, ValueError, AttributeError) as e:
+        info["reason"] = "%s: %s" % (type(e).__name__, e)
+    return info
 
 
 def bind_to_gpu(local_index, kfd_root=KFD_NODES, pci_root=PCI_DEVICES, apply=True, expected_devices=None):
