@@ -42,6 +42,16 @@ class Env:
     def turn(self):
         return len(self._gameboard.moves)                         # env.py:65-66
 
+    def _reward(self):
+        """env.py:87-112 (a helper `step` does not call): player 1's reward from the full check_win pair — the player whose
+        line was completed in the EARLIER round wins, a player with no line counts as round 10; equal rounds = 'otherwise'."""
+        p1_round, p2_round = self._gameboard.check_win()
+        p1 = 10 if p1_round < 0 else p1_round
+        p2 = 10 if p2_round < 0 else p2_round
+        if p1 == p2:
+            return self._reward_map["otherwise"]
+        return self._reward_map["win" if p1 < p2 else "loss"]
+
     def _observation(self):
         # env.py:68-85.  Pure list bookkeeping over what qttt_export returned.
         board = self._gameboard.board

@@ -161,6 +161,17 @@ def test_spaces_match_reference_declarations():
     assert a.contains((3, 8)) and not a.contains((3, 9))
 
 
+def test_the_reference_package_layout_resolves_by_module_path():
+    """qtttgym/__init__.py:1-4 and its four modules: a caller that names `qtttgym.display.displayBoard` (strat_eval.py:44)
+    or imports `qtttgym.qeval` finds the same objects under this package."""
+    import importlib
+    import qtttgym_amd
+    for mod, name in (("board", "Board"), ("qeval", "QEvalClassic"), ("display", "displayBoard"), ("env", "Env")):
+        m = importlib.import_module("qtttgym_amd." + mod)
+        assert getattr(m, name) is getattr(qtttgym_amd, name)
+    assert callable(qtttgym_amd.Env._reward) and callable(qtttgym_amd.Env.observ) and callable(qtttgym_amd.Env.render)
+
+
 def test_display_board_matches_reference_layout(capsys):
     from qtttgym_amd.board import Board, QEvalClassic, displayBoard
     b = Board(QEvalClassic())

@@ -97,8 +97,8 @@ def test_reference_draws_one_bit_per_collapse_only():
 
 def test_host_side_mirrors_against_the_reference_live(capsys):
     """The pieces of the host mirror that are plain Python (no device work) against the imported reference:
-    `displayBoard` prints what display.py:4-32 prints for the same attributes, and `ind2move` / `move2ind`
-    (qtttgym_amd.actions) are mcts.py:339-350's tables."""
+    `displayBoard` prints what display.py:4-32 prints for the same attributes, `Env._reward` is env.py:87-112 for every
+    check_win pair, and `ind2move` / `move2ind` (qtttgym_amd.actions) are mcts.py:339-350's tables."""
     import sys
     from ref_shim import REFERENCE_ROOT
     qtttgym, src = load_reference()
@@ -122,6 +122,22 @@ def test_host_side_mirrors_against_the_reference_live(capsys):
         mine.moves, mine.board = list(gb.moves), list(gb.board)
         displayBoard(mine)
         assert capsys.readouterr().out == want
+    # Env._reward (env.py:87-112, a helper step() does not call): same value for every check_win pair
+    from qtttgym_amd.env import Env as MyEnv
+
+    class FixedBoard:
+        def __init__(self, pair):
+            self.pair = pair
+
+        def check_win(self):
+            return self.pair
+    ref_env = qtttgym.Env()
+    for p1 in range(-1, 10):
+        for p2 in range(-1, 10):
+            mine_env, ref_env._gameboard = Attrs(), FixedBoard((p1, p2))
+            mine_env._gameboard, mine_env._reward_map = FixedBoard((p1, p2)), dict(ref_env._reward_map)
+            got, want = MyEnv._reward(mine_env), ref_env._reward()
+            assert type(got) is type(want) and got == want, (p1, p2, got, want)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     import mcts as ref_mcts
