@@ -156,8 +156,9 @@ static int adopt(PyObject *board, PyObject *moves, PyObject *bd, PyObject *qs, c
                 if (eq < 0) { Py_DECREF(spare); Py_DECREF(nw); return -1; }
                 if (eq) {
                     Py_INCREF(t);
-                    PyList_SetItem(nw, k, t);             /* steals t, drops s */
-                    PySequence_DelItem(spare, j);
+                    if (PyList_SetItem(nw, k, t) < 0 || PySequence_DelItem(spare, j) < 0) {   /* SetItem steals t, drops s */
+                        Py_DECREF(spare); Py_DECREF(nw); return -1;
+                    }
                     break;
                 }
             }
@@ -180,8 +181,9 @@ static int adopt(PyObject *board, PyObject *moves, PyObject *bd, PyObject *qs, c
                     if (!u) { Py_DECREF(spare); Py_DECREF(nw); return -1; }
                     Py_DECREF(u);
                     Py_INCREF(t);
-                    PyList_SetItem(nw, k, t);
-                    PySequence_DelItem(spare, hit);
+                    if (PyList_SetItem(nw, k, t) < 0 || PySequence_DelItem(spare, hit) < 0) {
+                        Py_DECREF(spare); Py_DECREF(nw); return -1;
+                    }
                 }
             }
         }
@@ -211,8 +213,9 @@ static PyObject *fb_init(PyObject *self, PyObject *args) {
 }
 
 /* board_op(board, op, lo, hi, bit, drop_last_move, stream) -> 0 done | -100 declined (use the Python path) | rc of the
- * library (> 0 hipError_t, < 0 argument error).  The GIL is held throughout: it is what serialises the one staging
- * record (the call spins for ~10 us; CPython's switch interval is 5 ms). */
+ * library (> 0 hipError_t, < 0 argument error).  The CALLER serialises the one staging record (board.py holds
+ * _Staging.lock around this function); the GIL is released for the device round trip alone, like the ctypes call of the
+ * Python path — normally ~5 us of polling, but a stream synchronise when the poll gives up behind a long kernel. */
 static PyObject *fb_board_op(PyObject *self, PyObject *args) {
     PyObject *board;
     int op, lo, hi, bit, drop_last;
@@ -221,7 +224,10 @@ static PyObject *fb_board_op(PyObject *self, PyObject *args) {
     if (!g_op_host || !g_in || !g_out) { PyErr_SetString(PyExc_RuntimeError, "_fastboard.init() was not called"); return NULL; }
     PyObject *moves, *bd, *qs;
     if (pack(board, op, lo, hi, bit, drop_last, &moves, &bd, &qs) != 0) return PyLong_FromLong(DECLINE);
-    int rc = g_op_host(g_in, g_out, 1, (void *)(uintptr_t)stream);
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = g_op_host(g_in, g_out, 1, (void *)(uintptr_t)stream);
+    Py_END_ALLOW_THREADS
     if (rc == 0) {
         uint8_t r[64];
         memcpy(r, g_out, 64);
