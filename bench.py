@@ -298,11 +298,13 @@ VALU_PEAK_GINST = 1024 / 1.03
 
 
 def kernel_label(mode, bpl, blk):
+    """the kernel's name as rocprofv3 prints it (template arguments: BLOCK, BPL, HAS_BITS, AUTO_RESET, SAMPLE, OBS, DEVSTEP /
+    BLOCK, AUTO_RESET, RETURNS — qttt_step_kernels.h), so that the line can be held against profiles/*/kernel_stats*.csv"""
     if mode == "random-fused":
-        return "step_random_fused_kernel<256, true>"
+        return "step_random_fused_kernel<256, true, false>"
     if mode == "random":
-        return "step_kernel<%d, %d, false, true, true, false>" % (blk, bpl)
-    step = "step_kernel<%d, %d, false, true, false, %s>" % (blk, bpl, "true" if mode == "gym" else "false")
+        return "step_kernel<%d, %d, false, true, true, false, false>" % (blk, bpl)
+    step = "step_kernel<%d, %d, false, true, false, %s, false>" % (blk, bpl, "true" if mode == "gym" else "false")
     return ("sample_actions_kernel + " + step) if mode == "policy" else step
 
 
@@ -502,7 +504,7 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
     return out
 
 
-# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true>: 141 635 277 per dispatch of 1 048 576 boards x
+# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true, false>: 141 635 277 per dispatch of 1 048 576 boards x
 # 64 steps = 8 644.7 per wave = 135.1 per ply (profiles/r05/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass;
 # round 4: 148.3)
 FUSED_VALU_PER_STEP = 135.1
