@@ -385,13 +385,27 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
     const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
     // 256-thread workgroups: the finest spread of a small batch over the 256 CUs (4 096 boards = 16 CUs
     // with 512 threads, 16 with 256 — but 262 144 boards = 1 024 workgroups, four per CU, instead of two)
+    // at most FUSED_MAX_PLIES plies per launch (their keys travel as a kernel argument); a longer run is that many launches,
+    // the boards going through HBM in between (32 bytes per board and 64 plies).  With out_stride == 0 only the LAST ply's
+    // outputs are kept, so the earlier launches of such a run write none.
 #define QTTT_RF(AR, RT) hipLaunchKernelGGL((step_random_fused_kernel<256, AR, RT>), dim3(blocks_for(n, 256)), dim3(256), 0, s, \
-                                           p.P, p.Q, (u64)seed, step_idx0, (u64)board_offset, a16, rb, terminated,    \
-                                           out_stride, n, n_steps, returns)
-    if (returns) { if (ar) QTTT_RF(true, true); else QTTT_RF(false, true); }
-    else         { if (ar) QTTT_RF(true, false); else QTTT_RF(false, false); }
+                                           p.P, p.Q, keys, (u64)board_offset, a_c, r_c, t_c, out_stride, n, plies, returns)
+    for (int32_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
+        const int32_t plies = n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES;
+        const bool last = done + plies == n_steps;
+        FusedKeys keys;
+        for (int32_t t = 0; t < FUSED_MAX_PLIES; ++t) keys.k[t] = launch_key(seed, step_idx0 + (u32)(done + (t < plies ? t : 0)));
+        const bool writes = out_stride != 0 || last;
+        uint16_t *a_c = (a16 && writes) ? a16 + (int64_t)done * out_stride : nullptr;
+        u32 *r_c = (rb && writes) ? rb + (int64_t)done * out_stride : nullptr;
+        uint8_t *t_c = (terminated && writes) ? terminated + (int64_t)done * out_stride : nullptr;
+        if (returns) { if (ar) QTTT_RF(true, true); else QTTT_RF(false, true); }
+        else         { if (ar) QTTT_RF(true, false); else QTTT_RF(false, false); }
+        const int rc = launch_status();
+        if (rc) return rc;
+    }
 #undef QTTT_RF
-    return launch_status();
+    return 0;
 }
 
 int qttt_observe(const void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len,

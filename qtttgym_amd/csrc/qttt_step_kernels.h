@@ -253,9 +253,14 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
 //   nth9 / policy_action_nth9: qttt_state.h (the full 4.5 KB "r-th empty square" table, computed by the workgroup).
 // With AUTO_RESET the policy always has a legal pair (a board that is not done has >= 2 empty squares:
 // 8 classical squares set the done bit), so the step runs TRUSTED (no validation, no sorting).
+// The launch keys of the plies come from the host as a kernel argument (FusedKeys, at most FUSED_MAX_PLIES per launch; the
+// library splits longer runs): splitmix64 per ply on the scalar unit was 25 of the loop's 86 scalar instructions — free at
+// eight waves per SIMD, but in a wave's own in-order stream, which is what a small batch (<= 4 waves per SIMD) is bound by.
+constexpr int FUSED_MAX_PLIES = 64;
+struct FusedKeys { u64 k[FUSED_MAX_PLIES]; };
 template <int BLOCK, bool AUTO_RESET, bool RETURNS = false>
 __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
-    u64 *__restrict__ pP, u64 *__restrict__ pQ, u64 seed, u32 step_idx0, u64 board_offset,
+    u64 *__restrict__ pP, u64 *__restrict__ pQ, FusedKeys keys, u64 board_offset,
     uint16_t *__restrict__ actions_out, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
     int64_t out_stride, int64_t n, int32_t n_steps, float *__restrict__ returns) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
@@ -277,10 +282,12 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     uint16_t *a_blk = actions_out ? actions_out + ib : nullptr;
     u32 *r_blk = reward_bits ? reward_bits + ib : nullptr;
     uint8_t *t_blk = terminated ? terminated + ib : nullptr;
+    const int64_t a_step = actions_out ? out_stride : 0, r_step = reward_bits ? out_stride : 0;   // a null output stays null
     const u32 lane = threadIdx.x;
     u32 lines = 0;                                                  // plies whose reward was -1.0 (env.py:49): -(the return)
+    u64 key = keys.k[0];
     for (int32_t t = 0; t < n_steps; ++t) {
-        const u64 key = launch_key(seed, step_idx0 + (u32)t);       // wave-uniform: scalar unit
+        const u64 key_next = keys.k[(t + 1) & (FUSED_MAX_PLIES - 1)];   // one scalar load, requested a ply ahead
         const u32 h1 = lowbias32(id ^ (u32)key);
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
         u32 act, win;
@@ -303,8 +310,10 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
             }
         }
         if (RETURNS) lines += win & 1u;                             // (its own instantiation: the ordinary ply carries nothing extra)
-        if (a_blk) a_blk += out_stride;
-        if (r_blk) { r_blk += out_stride; t_blk += out_stride; }
+        a_blk += a_step;
+        r_blk += r_step;
+        t_blk += r_step;
+        key = key_next;
     }
     if (RETURNS) returns[i] -= (float)lines;                        // the sum of the rewards of these plies, accumulated
     store_stream(&pP[i], (u64)P0 | ((u64)P1 << 32));

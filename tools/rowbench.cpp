@@ -175,9 +175,11 @@ int main(int argc, char **argv) {
     CK(hipMemset(state, 0, s64 * 16));
     hipStream_t s; CK(hipStreamCreate(&s));
     Planes p = planes(state, n);
+    auto fused_keys = [](u64 seed) { FusedKeys k; for (int t = 0; t < FUSED_MAX_PLIES; ++t) k.k[t] = launch_key(seed, (u32)t); return k; };
     if (plies > 0)
         hipLaunchKernelGGL((step_random_fused_kernel<256, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.P, p.Q,
-                           (u64)7, 0u, (u64)0, (uint16_t *)nullptr, (u32 *)nullptr, (uint8_t *)nullptr, (int64_t)0, n, plies, (float *)nullptr);
+                           fused_keys(7), (u64)0, (uint16_t *)nullptr, (u32 *)nullptr, (uint8_t *)nullptr, (int64_t)0, n,
+                           plies < FUSED_MAX_PLIES ? plies : FUSED_MAX_PLIES, (float *)nullptr);
     CK(hipStreamSynchronize(s));
     ExpOut eo;
     CK(hipMalloc(&eo.moves, n * 18)); CK(hipMalloc(&eo.n_moves, n)); CK(hipMalloc(&eo.board, n * 9));
@@ -267,9 +269,10 @@ int main(int argc, char **argv) {
         Planes q2 = planes(st2, n);
         uint16_t *fa; u32 *fr; uint8_t *ft;
         CK(hipMalloc(&fa, (size_t)64 * n * 2)); CK(hipMalloc(&fr, (size_t)64 * n * 4)); CK(hipMalloc(&ft, (size_t)64 * n));
+        const FusedKeys k3 = fused_keys(3);
         vs.push_back({"random_fused 1 board/lane <256>, 64 plies (us per LAUNCH)", [=](hipStream_t st) {
             hipLaunchKernelGGL((step_random_fused_kernel<256, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                               q2.P, q2.Q, (u64)3, 0u, (u64)0, fa, fr, ft, (int64_t)n, n, 64, (float *)nullptr); }, {}});
+                               q2.P, q2.Q, k3, (u64)0, fa, fr, ft, (int64_t)n, n, 64, (float *)nullptr); }, {}});
 #define RF2(BLK)                                                                                                        \
         vs.push_back({"random_fused 2 boards/lane <" #BLK ">, 64 plies (us per LAUNCH)", [=](hipStream_t st) {          \
             hipLaunchKernelGGL((step_random_fused2_kernel<BLK>), dim3((unsigned)((n / 2 + BLK - 1) / BLK)), dim3(BLK), 0, st, \
