@@ -193,14 +193,31 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(
 // MCTS._simulate (mcts.py:185-198) under the uniform priors of mcts.py:287-292: play uniform-legal
 // random moves to the end with the board in registers.  Ply p uses the counter hash of
 // (seed, board id, step_idx0 + p) exactly like qttt_sample_actions + qttt_step would.
-// one playout of the board in (P0, P1, Q0, Q1) to the end; returns the number of plies played
-__device__ __forceinline__ u32 playout(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 id, u64 seed, u32 step_idx0,
+// The launch keys of a playout's plies come from a table in LDS (splitmix64 of (seed, step index): 25 scalar instructions
+// per ply when the step index is wave-uniform, and ~30 VECTOR instructions per ply when it differs per lane — the
+// simulations of rollout_many / expand_rollout use step_idx0 + slot * QTTT_SIM_STRIDE + ply).  A table row = the nine keys
+// of one slot; PLAYOUT_KEY_SLOTS rows fit one key per thread of a 256-thread workgroup.  More slots than that: the keys are
+// computed in the loop (TABLE = false).
+constexpr u32 PLAYOUT_PLIES = 9u, PLAYOUT_KEY_SLOTS = 28u;
+template <int BLOCK>
+__device__ __forceinline__ void fill_playout_keys_nosync(u64 *keytab, u64 seed, u32 step_idx0, u32 n_slots) {
+    for (u32 k = threadIdx.x; k < n_slots * PLAYOUT_PLIES; k += BLOCK) {
+        const u32 slot = k / PLAYOUT_PLIES, ply = k - slot * PLAYOUT_PLIES;
+        keytab[k] = launch_key(seed, step_idx0 + slot * QTTT_SIM_STRIDE + ply);
+    }
+}
+// one playout of the board in (P0, P1, Q0, Q1) to the end; returns the number of plies played.  TABLE: `keys` = the nine
+// keys of this lane's slot (LDS); else they are launch_key(seed, step_idx0 + ply).
+template <bool TABLE>
+__device__ __forceinline__ u32 playout(u32 &P0, u32 &P1, u32 &Q0, u32 &Q1, u32 id, u64 seed, u32 step_idx0, const u64 *keys,
                                        const uint8_t *lut, const uint8_t *plut, const uint8_t *nth9) {
     u32 played = 0;
-    for (u32 p = 0; p < 9u; ++p) {
+    u64 key_tab = TABLE ? keys[0] : 0ull;
+    for (u32 p = 0; p < PLAYOUT_PLIES; ++p) {
         const u32 empty = ~(P1 >> P1_CL_SHIFT) & 0x1FFu;
         if ((P1 >> 31) || (empty & (empty - 1u)) == 0u) break;   // terminal (mcts.py:188) / nothing legal
-        const u64 key = launch_key(seed, step_idx0 + p);
+        const u64 key = TABLE ? key_tab : launch_key(seed, step_idx0 + p);
+        if (TABLE) key_tab = keys[p + 1u < PLAYOUT_PLIES ? p + 1u : p];      // the next ply's, requested a ply ahead
         const u32 h1 = lowbias32(id ^ (u32)key);
         const u32 h2 = lowbias32(h1 ^ (u32)(key >> 32));
         const u32 act = policy_action_nth9(plut, nth9, empty, h2);   // the k-th legal pair, squares a < b
@@ -216,14 +233,16 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t plut[POLICY_LUT_WORDS * 4];
     __shared__ uint8_t nth9[NTH9_BYTES];
+    __shared__ u64 keytab[PLAYOUT_PLIES];
     int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     const u64 P = i < n ? pP[i] : 0ull, Q = i < n ? pQ[i] : 0ull;  // requested before the table fills
     fill_policy_lut<QTTT_BLOCK>(plut);
     fill_nth9<QTTT_BLOCK>(nth9);
+    fill_playout_keys_nosync<QTTT_BLOCK>(keytab, seed, step_idx0, 1u);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (i >= n) return;
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
-    const u32 played = playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed, step_idx0, lut, plut, nth9);
+    const u32 played = playout<true>(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed, step_idx0, keytab, lut, plut, nth9);
     const u64 oP = (u64)P0 | ((u64)P1 << 32), oQ = (u64)Q0 | ((u64)Q1 << 32);
     int w, t;
     lite_update_winner(lite_unpack(oP), lut, w, t);
@@ -247,13 +266,17 @@ __global__ __launch_bounds__(QTTT_BLOCK) void rollout_many_kernel(
     const int64_t i = jl / n_sims;                        // board
     const u32 sim = (u32)(jl - i * n_sims);
     const u64 P = pP[i], Q = pQ[i];                       // n_sims neighbouring lanes read the same 16 bytes
+    __shared__ u64 keytab[PLAYOUT_KEY_SLOTS * PLAYOUT_PLIES];
+    const bool table = n_sims <= PLAYOUT_KEY_SLOTS;       // wave-uniform
     fill_policy_lut<QTTT_BLOCK>(plut);
     fill_nth9<QTTT_BLOCK>(nth9);
+    if (table) fill_playout_keys_nosync<QTTT_BLOCK>(keytab, seed, step_idx0, n_sims);
     fill_line_lut<QTTT_BLOCK>(lut);                       // ends with the workgroup barrier
     if (j >= n_lanes) return;
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
-    const u32 played = playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed, step_idx0 + sim * QTTT_SIM_STRIDE,
-                               lut, plut, nth9);
+    const u32 id = fold_id(board_offset + (u64)i);
+    const u32 played = table ? playout<true>(P0, P1, Q0, Q1, id, seed, 0u, keytab + sim * PLAYOUT_PLIES, lut, plut, nth9)
+                             : playout<false>(P0, P1, Q0, Q1, id, seed, step_idx0 + sim * QTTT_SIM_STRIDE, nullptr, lut, plut, nth9);
     int w, t;
     lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, t);
     result[j] = (int8_t)(w < 0 ? 0 : (w ? 1 : -1));
@@ -283,6 +306,8 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
     __shared__ u64 htbl[PYKEY ? PYHASH_LUT_WORDS : 1];
     __shared__ u64 ltbl[512];
     __shared__ int acc[BLOCK];                                  // [pair of the workgroup][child]
+    __shared__ u64 keytab[PLAYOUT_KEY_SLOTS * PLAYOUT_PLIES];   // slot = child * n_sims + sim
+    const bool table = 2u * n_sims <= PLAYOUT_KEY_SLOTS;        // wave-uniform
     const u32 per_pair = 2u * n_sims;
     const u32 pl = threadIdx.x / per_pair;                      // pair of the workgroup
     const u32 rem = threadIdx.x - pl * per_pair;
@@ -297,6 +322,7 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
     fill_nth9<BLOCK>(nth9);
     if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
     if (out.legal) fill_legal_lut<BLOCK>(ltbl);
+    if (table) fill_playout_keys_nosync<BLOCK>(keytab, seed, step_idx0, 2u * n_sims);
     fill_line_lut<BLOCK>(lut);                                  // ends with the workgroup barrier
     int r = 0;
     u32 kids = 0;
@@ -316,8 +342,9 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_kernel(
         }
         if (child < kids) {
             u32 P0 = child ? P0b : P0a, P1 = child ? P1b : P1a;
-            playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)i), seed,
-                    step_idx0 + (child * n_sims + sim) * QTTT_SIM_STRIDE, lut, plut, nth9);
+            const u32 slot = child * n_sims + sim, id = fold_id(board_offset + (u64)i);
+            if (table) playout<true>(P0, P1, Q0, Q1, id, seed, 0u, keytab + slot * PLAYOUT_PLIES, lut, plut, nth9);
+            else playout<false>(P0, P1, Q0, Q1, id, seed, step_idx0 + slot * QTTT_SIM_STRIDE, nullptr, lut, plut, nth9);
             int w, t;
             lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, t);
             r = w < 0 ? 0 : (w ? 1 : -1);                       // MCTS._reward, mcts.py:200-209
@@ -361,6 +388,8 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
     __shared__ int acc[XR_MAX_PAIRS * 2];
     __shared__ uint16_t unit_tbl[XR_MAX_PAIRS * 2];             // unit -> pair << 1 | child
     __shared__ u32 wave_tot[BLOCK / 64];
+    __shared__ u64 keytab[PLAYOUT_KEY_SLOTS * PLAYOUT_PLIES];   // slot = child * n_sims + sim
+    const bool table = 2u * n_sims <= PLAYOUT_KEY_SLOTS;        // wave-uniform
     const u32 t = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * pairs_per_block;
     const int64_t i = base + t;
@@ -375,6 +404,7 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
     fill_nth9<BLOCK>(nth9);
     if (PYKEY) fill_pyhash_lut<BLOCK>(htbl);
     if (out.legal) lw.store(ltbl);
+    if (table) fill_playout_keys_nosync<BLOCK>(keytab, seed, step_idx0, 2u * n_sims);
     fill_line_lut<BLOCK>(lut);                                  // ends with the workgroup barrier
     // ---- 1. the expansions
     u32 kids = 0;
@@ -423,8 +453,9 @@ __global__ __launch_bounds__(BLOCK) void expand_rollout_jobs_kernel(
         u32 P0 = (u32)cP, P1 = (u32)(cP >> 32), Q0 = (u32)cQ, Q1 = (u32)(cQ >> 32);
         const u32 child_real = (P1 >> P1_N_SHIFT) & 0xFu;
         const int64_t ip = base + pl;
-        playout(P0, P1, Q0, Q1, fold_id(board_offset + (u64)ip), seed, step_idx0 + (child * n_sims + sim) * QTTT_SIM_STRIDE,
-                lut, plut, nth9);
+        const u32 slot = child * n_sims + sim, id = fold_id(board_offset + (u64)ip);
+        if (table) playout<true>(P0, P1, Q0, Q1, id, seed, 0u, keytab + slot * PLAYOUT_PLIES, lut, plut, nth9);
+        else playout<false>(P0, P1, Q0, Q1, id, seed, step_idx0 + slot * QTTT_SIM_STRIDE, nullptr, lut, plut, nth9);
         int w, tm;
         lite_update_winner(lite_unpack((u64)P0 | ((u64)P1 << 32)), lut, w, tm);
         const int r = w < 0 ? 0 : (w ? 1 : -1);                 // MCTS._reward, mcts.py:200-209
