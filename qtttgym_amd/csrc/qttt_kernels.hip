@@ -353,13 +353,23 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
         hipStream_t s = (hipStream_t)stream;
         const uint16_t *a16 = reinterpret_cast<const uint16_t *>(actions);
         u32 *rb = reinterpret_cast<u32 *>(reward);
-#define QTTT_FUSED(HB, AR)                                                                        \
-    hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.P, p.Q, a16, bits, (u64)seed, \
-                       step_idx0, hi_fold, (u32)first, rb, terminated, out_stride, n, n_steps)
-        if (bits) { if (ar) QTTT_FUSED(true, true); else QTTT_FUSED(true, false); }
-        else      { if (ar) QTTT_FUSED(false, true); else QTTT_FUSED(false, false); }
+        // at most FUSED_MAX_PLIES plies per launch (their keys travel as a kernel argument): a longer run is that many
+        // launches.  With out_stride == 0 every launch writes its last ply's outputs to the same place; the run's last wins.
+#define QTTT_FUSED(HB, AR)                                                                                    \
+    hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.P, p.Q, a16 + (int64_t)done * n,            \
+                       bits ? bits + (int64_t)done * n : nullptr, keys, hi_fold, (u32)first,                   \
+                       rb + (int64_t)done * out_stride, terminated + (int64_t)done * out_stride, out_stride, n, plies)
+        for (int32_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
+            const int32_t plies = n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES;
+            FusedKeys keys;
+            for (int32_t t = 0; t < FUSED_MAX_PLIES; ++t) keys.k[t] = launch_key(seed, step_idx0 + (u32)(done + (t < plies ? t : 0)));
+            if (bits) { if (ar) QTTT_FUSED(true, true); else QTTT_FUSED(true, false); }
+            else      { if (ar) QTTT_FUSED(false, true); else QTTT_FUSED(false, false); }
+            const int rc = launch_status();
+            if (rc) return rc;
+        }
 #undef QTTT_FUSED
-        return launch_status();
+        return 0;
     }
     for (int32_t t = 0; t < n_steps; ++t) {
         int rc = qttt_step(state, actions + (int64_t)t * 2 * n, bits ? bits + (int64_t)t * n : nullptr,

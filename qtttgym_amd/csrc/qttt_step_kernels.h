@@ -210,35 +210,56 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(
 // the loop is VALU-bound and pays one launch instead of T.  Same results as T launches of
 // step_kernel; meant for replay / evaluation where the actions are known up front (a policy that
 // looks at the state between steps needs the one-launch-per-step form).
+// The launch keys of the plies come from the host as a kernel argument (FusedKeys, at most FUSED_MAX_PLIES per launch; the
+// library splits longer runs): splitmix64 per ply on the scalar unit was 25 of the loop's 86 scalar instructions — measured:
+// 3.57 -> 3.44 us per ply at 1 M boards, 1.19 -> 1.10 at 262 144 (profiles/r05/fused_kernarg_keys_check.txt).
+constexpr int FUSED_MAX_PLIES = 64;
+struct FusedKeys { u64 k[FUSED_MAX_PLIES]; };
 template <bool HAS_BITS, bool AUTO_RESET>
 __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, const uint16_t *__restrict__ actions,
-    const uint8_t *__restrict__ bits, u64 seed, u32 step_idx0, u32 id_hi_fold, u32 id_base,
+    const uint8_t *__restrict__ bits, FusedKeys keys, u32 id_hi_fold, u32 id_base,
     u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated, int64_t out_stride, int64_t n,
     int32_t n_steps) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
+    const int64_t ib = (int64_t)blockIdx.x * QTTT_BLOCK;            // first board of the workgroup (block-uniform)
+    const int64_t i = ib + threadIdx.x;
+    const int64_t il = i < n ? i : 0;                               // idle lanes re-read board 0, store nothing
+    const u64 P = load_stream(&pP[il]), Q = load_stream(&pQ[il]);   // requested before the table fills
     fill_line_lut<QTTT_BLOCK>(lut);
-    const int64_t i = (int64_t)blockIdx.x * QTTT_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const u64 P = pP[i], Q = pQ[i];
     u32 P0 = (u32)P, P1 = (u32)(P >> 32), Q0 = (u32)Q, Q1 = (u32)(Q >> 32);
-    const u32 id = id_base + (u32)i;
+    const u32 id = (id_base + (u32)i) ^ id_hi_fold;
+    // per-ply streams: a block-uniform 64-bit base (scalar unit, advanced by the stride every ply) plus the lane's offset
+    const uint16_t *a_blk = actions + ib;
+    const uint8_t *b_blk = HAS_BITS ? bits + ib : nullptr;
+    u32 *r_blk = reward_bits + ib;
+    uint8_t *t_blk = terminated + ib;
+    const u32 lane = threadIdx.x;
     u32 win = 0;
+    u64 key = keys.k[0];
+    u32 act = load_stream(&a_blk[lane]), bit_in = HAS_BITS ? (u32)load_stream(&b_blk[lane]) : 0u;
     for (int32_t t = 0; t < n_steps; ++t) {
-        const u32 act = load_stream(&actions[(int64_t)t * n + i]);
-        u32 bit;
-        if (HAS_BITS) bit = load_stream(&bits[(int64_t)t * n + i]) & 1u;
-        else bit = collapse_bit_of(id ^ ((u32)launch_key(seed, step_idx0 + (u32)t) ^ id_hi_fold));
+        const u64 key_next = keys.k[(t + 1) & (FUSED_MAX_PLIES - 1)];   // one scalar load, requested a ply ahead
+        // the next ply's action (and bit) are requested before this ply's step: their latency hides behind it
+        const bool more = t + 1 < n_steps;
+        a_blk += more ? n : 0;
+        if (HAS_BITS) b_blk += more ? n : 0;
+        const u32 act_next = load_stream(&a_blk[lane]), bit_next = HAS_BITS ? (u32)load_stream(&b_blk[lane]) : 0u;
+        const u32 bit = HAS_BITS ? (bit_in & 1u) : collapse_bit_of(id ^ (u32)key);
         win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, act, bit, lut);
         if (out_stride != 0 || t == n_steps - 1) {
-            const u32 rwv = 0x80000000u | (win << 23);
-            const uint8_t tmv = (uint8_t)(P1 >> 31);
-            store_stream(&reward_bits[(int64_t)t * out_stride + i], rwv);
-            store_stream(&terminated[(int64_t)t * out_stride + i], tmv);
+            store_stream(&r_blk[lane], 0x80000000u | (win << 23));
+            store_stream(&t_blk[lane], (uint8_t)(P1 >> 31));
         }
+        r_blk += out_stride;
+        t_blk += out_stride;
+        key = key_next;
+        act = act_next;
+        bit_in = bit_next;
     }
-    pP[i] = (u64)P0 | ((u64)P1 << 32);
-    pQ[i] = (u64)Q0 | ((u64)Q1 << 32);
+    store_stream(&pP[i], (u64)P0 | ((u64)P1 << 32));
+    store_stream(&pQ[i], (u64)Q0 | ((u64)Q1 << 32));
 }
 
 // The same with the uniform-legal policy IN the kernel (qttt_step_random_many): T consecutive
@@ -253,11 +274,6 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
 //   nth9 / policy_action_nth9: qttt_state.h (the full 4.5 KB "r-th empty square" table, computed by the workgroup).
 // With AUTO_RESET the policy always has a legal pair (a board that is not done has >= 2 empty squares:
 // 8 classical squares set the done bit), so the step runs TRUSTED (no validation, no sorting).
-// The launch keys of the plies come from the host as a kernel argument (FusedKeys, at most FUSED_MAX_PLIES per launch; the
-// library splits longer runs): splitmix64 per ply on the scalar unit was 25 of the loop's 86 scalar instructions — free at
-// eight waves per SIMD, but in a wave's own in-order stream, which is what a small batch (<= 4 waves per SIMD) is bound by.
-constexpr int FUSED_MAX_PLIES = 64;
-struct FusedKeys { u64 k[FUSED_MAX_PLIES]; };
 template <int BLOCK, bool AUTO_RESET, bool RETURNS = false>
 __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, FusedKeys keys, u64 board_offset,
