@@ -504,15 +504,15 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
     return out
 
 
-# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true, false>: 141 635 277 per dispatch of 1 048 576 boards x
-# 64 steps = 8 644.7 per wave = 135.1 per ply (profiles/r05/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass;
-# round 4: 148.3)
-FUSED_VALU_PER_STEP = 135.1
+# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true, false>: 142 761 677 per dispatch of 1 048 576 boards x
+# 64 steps = 8 713.5 per wave = 136.1 per ply (profiles/r05/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass;
+# round 4: 148.3); SQ_INSTS_SALU 28.4 executed per wave and ply since the plies' keys travel as a kernel argument
+FUSED_VALU_PER_STEP = 136.1
 # issue time of that instruction mix per wave and ply (tools/isa_budget.py --loop, profiles/r05/isa_budget_random_fused.txt:
-# 65.0 of the 135.1 in the fast class at 1.03 ns per instruction per SIMD, 70.1 in the slow class at 1.75 — a literal
+# 65.0 of the 136.1 in the fast class at 1.03 ns per instruction per SIMD, 71.1 in the slow class at 1.75 — a literal
 # operand does not make a logic instruction slow, an SGPR operand does: profiles/r02/valu_rates.txt): what a SIMD needs
 # per resident wave and ply when it never idles
-FUSED_ISSUE_NS_PER_WAVE_PLY = 189.6
+FUSED_ISSUE_NS_PER_WAVE_PLY = 191.4
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):
