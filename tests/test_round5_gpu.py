@@ -211,3 +211,56 @@ def test_board_facade_on_the_golden_episodes_with_and_without_the_mailbox(mailbo
     out = _run_script(_MAILBOX_SCRIPT % (ROOT, golden), QTTT_BOARD_MAILBOX_US=mailbox_us)
     info = json.loads(out.stdout.strip().splitlines()[-2])
     assert info["calls"] > 500 and info["fast"] is True           # qtttgym_amd/_fastboard.so is built and in use on the box
+
+
+# ---------------------------------------------------------------------------------------- fused runs of more than one launch
+@pytest.mark.parametrize("T", [65, 130, 200])
+@pytest.mark.parametrize("auto_reset", [True, False])
+@pytest.mark.parametrize("off", [12345, (1 << 32) - 2000])     # inside one 2^32 block of ids (the FUSED replay kernel) / across
+def test_fused_runs_longer_than_the_64_plies_of_one_launch(T, auto_reset, off):
+    """The fused kernels take at most 64 plies per launch (their launch keys travel as a kernel argument); the library
+    splits a longer run.  Same results as the launch-by-launch forms (which the oracle tests pin): every ply's outputs,
+    last-ply-only outputs, the accumulated returns, the state — for qttt_step_random_many and qttt_step_many(FUSED),
+    the latter with hashed and with explicit collapse bits."""
+    import torch
+    from qtttgym_amd import VecEnv
+    n, seed = 5003, 77 + T
+    mk = lambda: VecEnv(n, seed=seed, auto_reset=auto_reset, board_offset=off)
+    # launch by launch: the recording
+    rec = mk()
+    acts = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
+    rew = torch.empty((T, n), dtype=torch.float32, device="cuda")
+    term = torch.empty((T, n), dtype=torch.bool, device="cuda")
+    for t in range(T):
+        r, tm = rec.step_random(actions_out=acts[t])
+        rew[t], term[t] = r, tm
+    # qttt_step_random_many, every ply kept + returns
+    a = mk()
+    aa, ra, ta = torch.zeros_like(acts), torch.zeros_like(rew), torch.zeros_like(term)
+    ret = torch.zeros(n, dtype=torch.float32, device="cuda")
+    a.step_random_many(T, actions_out=aa, reward=ra, terminated=ta, returns=ret)
+    assert torch.equal(aa, acts) and torch.equal(ra.view(torch.int32), rew.view(torch.int32)) and torch.equal(ta, term)
+    assert torch.equal(a.state, rec.state) and a.step_idx == T
+    assert torch.equal(ret, rew.sum(dim=0))
+    # last ply only
+    b = mk()
+    last = torch.zeros((n, 2), dtype=torch.uint8, device="cuda")
+    r, tm = b.step_random_many(T, actions_out=last)
+    assert torch.equal(last, acts[-1]) and torch.equal(r.view(torch.int32), rew[-1].view(torch.int32)) and torch.equal(tm, term[-1])
+    assert torch.equal(b.state, rec.state)
+    # qttt_step_many(FUSED) on the recorded actions, hashed bits: the same boards again
+    c = mk()
+    rc, tc = torch.zeros_like(rew), torch.zeros_like(term)
+    c.step_many(acts, reward=rc, terminated=tc, fused=True)
+    assert torch.equal(rc.view(torch.int32), rew.view(torch.int32)) and torch.equal(tc, term) and torch.equal(c.state, rec.state)
+    d = mk()
+    r, tm = d.step_many(acts, fused=True)
+    assert torch.equal(r.view(torch.int32), rew[-1].view(torch.int32)) and torch.equal(tm, term[-1]) and torch.equal(d.state, rec.state)
+    # ... and with explicit bits against its own launch-by-launch form
+    bits = torch.randint(0, 2, (T, n), dtype=torch.uint8, device="cuda")
+    e, f = mk(), mk()
+    re_, te = torch.zeros_like(rew), torch.zeros_like(term)
+    e.step_many(acts, bits, reward=re_, terminated=te, fused=True)
+    rf, tf = torch.zeros_like(rew), torch.zeros_like(term)
+    f.step_many(acts, bits, reward=rf, terminated=tf, fused=False)
+    assert torch.equal(re_.view(torch.int32), rf.view(torch.int32)) and torch.equal(te, tf) and torch.equal(e.state, f.state)
