@@ -46,8 +46,8 @@ extern "C" {
     ((((uint32_t)(boards_per_lane) & 7u) << 8) |                                                  \
      ((workgroup_size) == 256 ? 1u << 12 : (workgroup_size) == 512 ? 2u << 12 : (workgroup_size) == 1024 ? 3u << 12 : 0u))
 
-#define QTTT_FLAG_FUSED 2u        /* qttt_step_many only: run the n_steps steps in ONE launch with the
-                                     boards held in registers (same results; for replay / evaluation
+#define QTTT_FLAG_FUSED 2u        /* qttt_step_many only: run the n_steps steps in ONE launch per 64 steps with
+                                     the boards held in registers (same results; for replay / evaluation
                                      where all actions are known up front) */
 
 int     qttt_abi_version(void);
@@ -92,7 +92,8 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
                    void *stream);
 
 /* n_steps consecutive qttt_step_random steps (policy -> collapse bit -> step, ply t keyed by the counter
- * hash of (seed, board_offset + i, step_idx0 + t)) in ONE launch with the boards in registers: the
+ * hash of (seed, board_offset + i, step_idx0 + t)) in ONE launch per 64 plies (the plies' launch keys travel as a
+ * kernel argument; a longer run is ceil(n_steps / 64) launches, same results) with the boards in registers: the
  * policy -> step loop of MCTS._simulate (mcts.py:185-198) as the env's random-policy throughput mode
  * (with QTTT_FLAG_AUTO_RESET a finished board restarts on its next ply).  Bit-identical to n_steps calls
  * of qttt_step_random.  Step t writes actions_out + 2*t*out_stride, reward + t*out_stride and
