@@ -228,7 +228,7 @@ def test_outcome_distribution_matches_reference_statistics():
     assert np.array_equal(r[both], np.where(p1[both] < p2[both], 1, -1))
 
 
-@pytest.mark.parametrize("n,sims", [(1, 1), (3, 7), (1000, 10), (65536, 10), (4099, 33)])
+@pytest.mark.parametrize("n,sims", [(1, 1), (3, 7), (1000, 10), (65536, 10), (4099, 33), (500, 28), (500, 29)])   # 28 = the key table's slots
 def test_rollout_many_columns_equal_single_rollouts(n, sims):
     """qttt_rollout_many = MCTS._rollout's num_simulations loop (mcts.py:170-176) in one launch: column s is
     qttt_rollout(step_idx0 + 16 s) — which the tests above hold against the oracle's playout loop."""

@@ -119,7 +119,8 @@ def test_expand_rollout_children_against_the_oracle_playout_loop(gp):
 
 
 @pytest.mark.parametrize("n,sims", [(1, 1), (5, 3), (1000, 10), (65536, 1), (65536, 10), (4099, 33), (300, 128),
-                                    (100001, 3), (300000, 1), (8200, 128), (1 << 20, 2)])
+                                    (100001, 3), (300000, 1), (8200, 128), (1 << 20, 2),
+                                    (700, 14), (700, 15)])      # the last two: either side of the playout key table's 28 slots
 def test_expand_rollout_equals_expand_then_rollout_many(n, sims):
     """One launch == qttt_expand + qttt_rollout_many(child0, step_idx0) + qttt_rollout_many(child1, step_idx0 + 16 n_sims).
     Both mappings of the operator are covered: a lane per (pair, simulation, child) below 262 144 playouts, the
