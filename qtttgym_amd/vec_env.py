@@ -205,7 +205,7 @@ class VecEnv:
         """T consecutive steps from pre-recorded device tensors actions u8[T,N,2] (bits u8[T,N]),
         enqueued from C with no per-step host work.  With `reward`/`terminated` of shape [T,N]
         every step's outputs are kept; otherwise only the last step's (returned).
-        fused=True runs all T steps in one launch with the boards in registers (same results)."""
+        fused=True runs the T steps with the boards in registers, one launch per 64 steps (same results)."""
         n = self.num_envs
         T = int(actions.shape[0])
         if actions.dtype != torch.uint8 or not actions.is_contiguous() or tuple(actions.shape) != (T, n, 2) \
@@ -393,8 +393,8 @@ class VecEnv:
         return out
 
     def step_random_many(self, n_steps, actions_out=None, reward=None, terminated=None, returns=None):
-        """n_steps steps under the in-kernel uniform-legal policy in ONE launch with the boards in
-        registers (qttt_step_random_many) == n_steps calls of step_random().  With reward f32[T,N] +
+        """n_steps steps under the in-kernel uniform-legal policy with the boards in registers, ONE launch per
+        64 plies (qttt_step_random_many) == n_steps calls of step_random().  With reward f32[T,N] +
         terminated bool[T,N] (and optionally actions_out u8[T,N,2]) every step's outputs are kept; without
         them only the last step's are written (to the environment's own reward / terminated buffers, which
         are returned; actions_out u8[N,2] optional).  returns f32[N] (optional) is ACCUMULATED: += the sum of each
