@@ -81,7 +81,7 @@ def parse_args(argv=None):
                     help="boards over ALL GPUs, sharded with dist.shard_range (strong scaling; "
                          "2097152 with --gpus 8 = BASELINE config 4); overrides --boards")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (other configs / modes) at N = 1")
-    ap.add_argument("--fused-steps", type=int, default=64, help="steps per launch of --mode random-fused")
+    ap.add_argument("--fused-steps", type=int, default=64, help="steps per launch of --mode random-fused (<= 64)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--regions", type=int, default=0, help="repeat count of the K-step timed region (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -848,8 +848,9 @@ def main():
     args = parse_args()
     ensure_built()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.boards < 1 or args.total_boards < 0 \
-            or args.fused_steps < 1 or (args.total_boards and args.total_boards < args.gpus):
-        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1, --total-boards >= --gpus")
+            or not 1 <= args.fused_steps <= 64 or (args.total_boards and args.total_boards < args.gpus):
+        raise SystemExit("need --gpus >= 1, --steps >= 1, --warmup >= 0, --boards >= 1, --total-boards >= --gpus, "
+                         "1 <= --fused-steps <= 64 (a fused launch holds at most 64 plies)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # before anything imports torch or touches the GPU
     sys.exit(run(args))
