@@ -19,7 +19,10 @@ perf_counter over the whole bracket (`host_wall_ms_per_step` = bracket time / (W
 reported beside it; it adds the host's synchronise latency, a fixed ~20-60 us per region).
 
 Multi-GPU.  Boards are independent: each rank owns B boards (global ids rank*B..), no data-path
-collective; one RCCL all_reduce of episode counters after the timed regions.  `--gpus N` with no
+collective.  The ranks' bookkeeping (the clock's barrier and MAX, rank count, per-rank timings, episode
+counters) is a few CPU scalars over gloo; the one real exchange, the gather of per-board returns after
+the timed regions, is device tensors over RCCL and runs under a deadline (QTTT_BENCH_GATHER_TIMEOUT,
+120 s): failing or hanging, it costs the line its `returns_gather` entry, never the value.  `--gpus N` with no
 WORLD_SIZE in the environment starts its own N ranks (one process per GPU) before anything touches
 the GPU; under torchrun the ranks are taken from the environment.  `ranks_seen` is an all_reduce
 of ones over the process group; the line is refused unless n_gpus == ranks_seen.
@@ -616,22 +619,35 @@ def run(args):
     # QTTT_DIST_FORCE=1: build the process group and run every collective of the N > 1 path with one
     # rank too (a one-GPU box can then exercise the RCCL branch; tests/test_bench_contract_gpu.py)
     use_dist = world > 1 or os.environ.get("QTTT_DIST_FORCE") == "1"
+    # Two planes.  CONTROL = the clock's barrier and MAX, the rank count, the per-rank timings, the episode counters, the
+    # agreement flags: a few CPU scalars over gloo on the loopback interface.  DATA = the one real exchange of the path, the
+    # gather of per-board returns: device tensors over RCCL (xGMI), brought up lazily by its first collective — inside the
+    # watchdog below, so that an RCCL that fails OR HANGS on a node this code has never seen costs the line its
+    # `returns_gather` entry and nothing else.  QTTT_BENCH_CONTROL=nccl puts the control plane on RCCL too (the layout
+    # of rounds 1 - 4: eager communicator, device tensors everywhere).
+    control = "nccl" if (backend == "nccl" and os.environ.get("QTTT_BENCH_CONTROL") == "nccl") else "gloo"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node by contract; the hostname may not resolve
         if world == 1 and "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(_free_port())
-        if backend == "nccl":
+        if backend == "nccl" and control == "nccl":
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        elif backend == "nccl":
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    cpu = torch.device("cpu")
+    coll_dev = dev if control == "nccl" else cpu                    # control plane
+    data_dev = dev if backend == "nccl" else cpu                    # the returns gather
 
     def barrier():
         if use_dist:
-            if backend == "nccl":
+            if control == "nccl":
                 dist.barrier(device_ids=[dev_index])
             else:
-                dist.barrier()
+                dist.all_reduce(torch.zeros(1, dtype=torch.int32))  # a CPU all_reduce over gloo is a barrier
 
     def all_max(x):
         if not use_dist:
@@ -679,6 +695,7 @@ def run(args):
         sys.stderr.write("bench.py: per-rank timing all_gather failed on rank %d: %r\n" % (rank, e))
 
     gather = None
+    hung = False
     if use_dist:
         # Everything below is OPTIONAL bookkeeping off the timed path (the step has no collective): a failure of
         # any of it — e.g. the very first RCCL gather on a node this code has never seen — is reported inside the
@@ -704,15 +721,24 @@ def run(args):
                 fail = os.environ.get("QTTT_BENCH_FAIL_GATHER")          # test hooks (tests/test_round4_gpu.py, test_round5_gpu.py)
                 if fail == "1" or (fail is not None and fail.startswith("rank") and int(fail[4:]) == rank):
                     raise RuntimeError("QTTT_BENCH_FAIL_GATHER=%s: injected failure of the returns gather" % fail)
-                ret = env._reward.clone().to(coll_dev)
+                ret = env._reward.clone().to(data_dev)
             except Exception as e:                               # noqa: BLE001
                 prep_error = e
                 sys.stderr.write("bench.py: returns gather could not be prepared on rank %d: %r\n" % (rank, e))
-            try:
+
+            def exchange():
                 if not agree(prep_error is None, coll_dev):
                     raise RuntimeError("skipped on every rank: %s" % ("this rank failed to prepare it: %s: %s"
                                        % (type(prep_error).__name__, prep_error) if prep_error is not None else
                                        "another rank failed to prepare it"))
+                hang = os.environ.get("QTTT_BENCH_HANG_GATHER")             # test hook: this rank never joins the exchange
+                if hang is not None and hang.startswith("rank") and int(hang[4:]) == rank:
+                    time.sleep(3600)
+                t_up = time.perf_counter()
+                if backend == "nccl":                                # the first device collective brings RCCL up
+                    dist.all_reduce(torch.ones(1, dtype=torch.int32, device=dev))
+                    torch.cuda.synchronize(dev)
+                up_ms = (time.perf_counter() - t_up) * 1e3
                 gather_returns(ret, dst=0)                           # untimed: connection set-up of the gather
                 torch.cuda.synchronize(dev)
                 barrier()
@@ -720,11 +746,33 @@ def run(args):
                 gathered = gather_returns(ret, dst=0)
                 torch.cuda.synchronize(dev)
                 tg = all_max(time.perf_counter() - tg0)
-                gather = {"ms": tg * 1e3, "bytes_per_rank": 4 * B, "backend": backend,
-                          "boards_gathered": None if gathered is None else int(gathered.numel())}
-            except Exception as e:                               # noqa: BLE001
+                return {"ms": tg * 1e3, "bytes_per_rank": 4 * B, "backend": backend, "bring_up_ms": up_ms,
+                        "boards_gathered": None if gathered is None else int(gathered.numel())}
+
+            # the exchange runs under a deadline: a collective that never returns must not take the measured value with it
+            import threading
+            limit = float(os.environ.get("QTTT_BENCH_GATHER_TIMEOUT", "120"))
+            box = {}
+
+            def guarded():
+                try:
+                    box["value"] = exchange()
+                except BaseException as e:                           # noqa: BLE001
+                    box["error"] = e
+            th = threading.Thread(target=guarded, daemon=True)
+            th.start()
+            th.join(limit)
+            if th.is_alive():
+                hung = True
+                sys.stderr.write("bench.py: returns gather still running after %.0f s on rank %d: reported as timed out; "
+                                 "the process group is abandoned\n" % (limit, rank))
+                gather = {"error": "TimeoutError: no answer within %.0f s (QTTT_BENCH_GATHER_TIMEOUT)" % limit, "backend": backend}
+            elif "error" in box:
+                e = box["error"]
                 sys.stderr.write("bench.py: returns gather failed on rank %d: %r\n" % (rank, e))
                 gather = {"error": "%s: %s" % (type(e).__name__, e), "backend": backend}
+            else:
+                gather = box["value"]
 
     rc = 0
     if rank == 0:
@@ -761,6 +809,7 @@ def run(args):
                            "boards_per_gpu": B, "boards_total": total, "state_bytes_per_board": state_bytes,
                            "parallelism": "shard%d" % world, "mode": args.mode,
                            "dist_backend": backend if use_dist else None,
+                           "control_backend": control if use_dist else None,
                            "self_launched": bool(os.environ.get("QTTT_BENCH_SELF_LAUNCHED")),
                            "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"),
                            "stream": "created, current" if own_stream else "legacy default",
@@ -819,6 +868,11 @@ def run(args):
                     "beyond_cache_us": g("beyond_infinity_cache_16777216_boards", "us_per_step"),
                     "beyond_cache_frac": g("beyond_infinity_cache_16777216_boards", "frac")}
             print(json.dumps(out), flush=True)
+    if hung:
+        # a collective of the exchange is still blocked in its thread: no further collective, no destroy — leave at once
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc if replay_ok else 1)
     if use_dist:
         barrier()
         dist.destroy_process_group()

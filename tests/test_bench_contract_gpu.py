@@ -148,6 +148,21 @@ def test_bench_line_survives_a_failing_returns_gather():
     assert e["returns_gather"] == {"skipped": "QTTT_BENCH_NO_GATHER=1"} and e["ranks_seen"] == 2
 
 
+def test_bench_line_survives_a_returns_gather_that_never_returns():
+    """The single-shot 8-GPU run must not lose its value to a collective that hangs (an RCCL this code has never run on
+    that node): the exchange runs under a deadline.  Here rank 1 never joins it (injected), rank 0 blocks in the gather;
+    after QTTT_BENCH_GATHER_TIMEOUT both give up, rank 0 prints the line with the error inside, every rank leaves with 0."""
+    import time
+    t0 = time.time()
+    d = run_bench("--gpus", "2", "--boards", "32768", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                  env={"QTTT_DIST_BACKEND": "gloo", "QTTT_BENCH_HANG_GATHER": "rank1", "QTTT_BENCH_GATHER_TIMEOUT": "8"})
+    assert time.time() - t0 < 150
+    assert d["n_gpus"] == 2 == d["ranks_seen"] and d["value"] > 0 and d["config"]["replay_matches_recording"] is True
+    assert "TimeoutError" in d["returns_gather"]["error"] and "ms" not in d["returns_gather"]
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["config"]["episodes_finished"] > 0
+    assert abs(d["value"] - 2 * 32768 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
 def test_bench_total_boards_is_strong_scaling():
     """BASELINE config 4's shape: a fixed total sharded over the ranks (here 2 ranks on the one GPU over gloo,
     an odd total so the shards differ by one board)."""
@@ -171,8 +186,15 @@ def test_bench_rccl_branch_with_one_rank():
     d = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs",
                   env={"QTTT_DIST_FORCE": "1", "QTTT_DIST_BACKEND": "nccl"})
     assert d["n_gpus"] == 1 == d["ranks_seen"] and d["config"]["dist_backend"] == "nccl"
+    assert d["config"]["control_backend"] == "gloo"              # bookkeeping over gloo, the exchange over RCCL
     assert d["returns_gather"]["backend"] == "nccl" and d["returns_gather"]["boards_gathered"] == 65536
+    assert d["returns_gather"]["bring_up_ms"] > 0                # the first device collective: RCCL really came up
     assert d["config"]["replay_matches_recording"] is True
+    # the layout of rounds 1 - 4 (everything on RCCL, eager communicator) stays available
+    c = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs",
+                  env={"QTTT_DIST_FORCE": "1", "QTTT_DIST_BACKEND": "nccl", "QTTT_BENCH_CONTROL": "nccl"})
+    assert c["config"]["control_backend"] == "nccl" and c["returns_gather"]["boards_gathered"] == 65536
+    assert c["config"]["episodes_finished"] == d["config"]["episodes_finished"]
     e = run_bench("--boards", "65536", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs")
     assert e["config"]["dist_backend"] is None and e["returns_gather"] is None
     assert e["config"]["episodes_finished"] == d["config"]["episodes_finished"]
