@@ -109,6 +109,22 @@ __device__ __forceinline__ void store_stream_sbase(void *block_base, u32 byte_of
     }
 }
 
+// ... and for the 1-, 2- and 4-byte per-ply outputs of the fused kernels (terminated, action, reward): the value travels
+// in the low bits of one register.
+template <int BYTES>
+__device__ __forceinline__ void store_stream_sbase_word(void *block_base, u32 byte_offset, u32 value) {
+    static_assert(BYTES == 1 || BYTES == 2 || BYTES == 4, "one register");
+#ifdef QTTT_NO_SBASE_STORES
+    if constexpr (BYTES == 1) store_stream(static_cast<uint8_t *>(block_base) + byte_offset, (uint8_t)value);
+    else if constexpr (BYTES == 2) store_stream(reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(block_base) + byte_offset), (uint16_t)value);
+    else store_stream(reinterpret_cast<u32 *>(static_cast<uint8_t *>(block_base) + byte_offset), value);
+    return;
+#endif
+    if constexpr (BYTES == 1) asm volatile("global_store_byte %0, %1, %2 nt" : : "v"(byte_offset), "v"(value), "s"(block_base) : "memory");
+    else if constexpr (BYTES == 2) asm volatile("global_store_short %0, %1, %2 nt" : : "v"(byte_offset), "v"(value), "s"(block_base) : "memory");
+    else asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(byte_offset), "v"(value), "s"(block_base) : "memory");
+}
+
 __device__ __forceinline__ u32 rotr32(u32 x, u32 s) { return __builtin_amdgcn_alignbit(x, x, s); }
 // v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xFFFFFFFF for 0
 __device__ __forceinline__ u32 ffbl_raw(u32 x) {

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
         const u32 bit = HAS_BITS ? (bit_in & 1u) : collapse_bit_of(id ^ (u32)key);
         win = step_core<AUTO_RESET>(P0, P1, Q0, Q1, act, bit, lut);
         if (out_stride != 0 || t == n_steps - 1) {
+            // (the compiler's own stores here: it counts them when it waits for the action requested a ply ahead)
             store_stream(&r_blk[lane], 0x80000000u | (win << 23));
             store_stream(&t_blk[lane], (uint8_t)(P1 >> 31));
         }
@@ -302,6 +303,10 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     const u32 lane = threadIdx.x;
     u32 lines = 0;                                                  // plies whose reward was -1.0 (env.py:49): -(the return)
     u64 key = keys.k[0];
+    // The state is consumed HERE, in front of the loop: the per-ply stores below are written out (store_stream_sbase_word),
+    // so the compiler sees no memory operation in the loop and would leave its wait for the state loads inside it — where
+    // a vmcnt wait also waits for the previous ply's stores (+9 % per ply with one wave per SIMD).
+    asm volatile("" : "+v"(P0), "+v"(P1), "+v"(Q0), "+v"(Q1));
     for (int32_t t = 0; t < n_steps; ++t) {
         const u64 key_next = keys.k[(t + 1) & (FUSED_MAX_PLIES - 1)];   // one scalar load, requested a ply ahead
         const u32 h1 = lowbias32(id ^ (u32)key);
@@ -319,10 +324,10 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
             win = step_core<false, false>(P0, P1, Q0, Q1, act, h1 >> 31, lut);
         }
         if (out_stride != 0 || t == n_steps - 1) {
-            if (a_blk) store_stream(&a_blk[lane], (uint16_t)act);
+            if (a_blk) store_stream_sbase_word<2>(a_blk, lane * 2u, act);
             if (r_blk) {
-                store_stream(&r_blk[lane], 0x80000000u | (win << 23));        // env.py:49: -1.0f / -0.0f
-                store_stream(&t_blk[lane], (uint8_t)(P1 >> 31));              // env.py:51
+                store_stream_sbase_word<4>(r_blk, lane * 4u, 0x80000000u | (win << 23));   // env.py:49: -1.0f / -0.0f
+                store_stream_sbase_word<1>(t_blk, lane, P1 >> 31);                          // env.py:51
             }
         }
         if (RETURNS) lines += win & 1u;                             // (its own instantiation: the ordinary ply carries nothing extra)
