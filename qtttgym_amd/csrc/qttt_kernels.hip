@@ -398,8 +398,13 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
     // at most FUSED_MAX_PLIES plies per launch (their keys travel as a kernel argument); a longer run is that many launches,
     // the boards going through HBM in between (32 bytes per board and 64 plies).  With out_stride == 0 only the LAST ply's
     // outputs are kept, so the earlier launches of such a run write none.
-#define QTTT_RF(AR, RT) hipLaunchKernelGGL((step_random_fused_kernel<256, AR, RT>), dim3(blocks_for(n, 256)), dim3(256), 0, s, \
-                                           p.P, p.Q, keys, (u64)board_offset, a_c, r_c, t_c, out_stride, n, plies, returns)
+#define QTTT_RFK(AR, RT, KP) hipLaunchKernelGGL((step_random_fused_kernel<256, AR, RT, KP>), dim3(blocks_for(n, 256)), dim3(256), 0, s, \
+                                               p.P, p.Q, keys, (u64)board_offset, a_c, r_c, t_c, out_stride, n, plies, returns)
+    // the instantiation without the per-ply "what is kept" tests, where it pays: one or two waves per SIMD are bound by a wave's
+    // own in-order stream (65 536 boards 0.59 -> 0.56 us per ply, 4 096: 0.58 -> 0.55), from four waves up the test-free loop
+    // is no faster and at 1 M boards 2 % slower (profiles/r05/fused_keep_instantiation_ab.txt, same box, alternating)
+    const bool keep_all = out_stride != 0 && a16 && rb && n < 262144;
+#define QTTT_RF(AR, RT) do { if (keep_all) QTTT_RFK(AR, RT, true); else QTTT_RFK(AR, RT, false); } while (0)
     for (int32_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
         const int32_t plies = n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES;
         const bool last = done + plies == n_steps;
@@ -415,6 +420,7 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
         if (rc) return rc;
     }
 #undef QTTT_RF
+#undef QTTT_RFK
     return 0;
 }
 

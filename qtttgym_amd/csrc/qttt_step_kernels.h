@@ -275,7 +275,9 @@ __global__ __launch_bounds__(QTTT_BLOCK) void step_fused_kernel(
 //   nth9 / policy_action_nth9: qttt_state.h (the full 4.5 KB "r-th empty square" table, computed by the workgroup).
 // With AUTO_RESET the policy always has a legal pair (a board that is not done has >= 2 empty squares:
 // 8 classical squares set the done bit), so the step runs TRUSTED (no validation, no sorting).
-template <int BLOCK, bool AUTO_RESET, bool RETURNS = false>
+// KEEP: every ply's action, reward and terminated are kept (out_stride != 0, no null output) — the loop then carries no
+// test of what to store.
+template <int BLOCK, bool AUTO_RESET, bool RETURNS = false, bool KEEP = false>
 __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
     u64 *__restrict__ pP, u64 *__restrict__ pQ, FusedKeys keys, u64 board_offset,
     uint16_t *__restrict__ actions_out, u32 *__restrict__ reward_bits, uint8_t *__restrict__ terminated,
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(BLOCK) void step_random_fused_kernel(
             act = (empty & (empty - 1u)) ? policy_action_nth9(plut, nth9, empty, h2) : 0u;
             win = step_core<false, false>(P0, P1, Q0, Q1, act, h1 >> 31, lut);
         }
-        if (out_stride != 0 || t == n_steps - 1) {
-            if (a_blk) store_stream_sbase_word<2>(a_blk, lane * 2u, act);
-            if (r_blk) {
+        if (KEEP || out_stride != 0 || t == n_steps - 1) {
+            if (KEEP || a_blk) store_stream_sbase_word<2>(a_blk, lane * 2u, act);
+            if (KEEP || r_blk) {
                 store_stream_sbase_word<4>(r_blk, lane * 4u, 0x80000000u | (win << 23));   // env.py:49: -1.0f / -0.0f
                 store_stream_sbase_word<1>(t_blk, lane, P1 >> 31);                          // env.py:51
             }
