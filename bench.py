@@ -300,11 +300,11 @@ def time_calls(torch, dev, fn, K, regions):
 VALU_PEAK_GINST = 1024 / 1.03
 
 
-def kernel_label(mode, bpl, blk):
+def kernel_label(mode, bpl, blk, boards=None):
     """the kernel's name as rocprofv3 prints it (template arguments: BLOCK, BPL, HAS_BITS, AUTO_RESET, SAMPLE, OBS, DEVSTEP /
-    BLOCK, AUTO_RESET, RETURNS — qttt_step_kernels.h), so that the line can be held against profiles/*/kernel_stats*.csv"""
+    BLOCK, AUTO_RESET, RETURNS, KEEP — qttt_step_kernels.h; KEEP below 262 144 boards with every output kept), so that the line can be held against profiles/*/kernel_stats*.csv"""
     if mode == "random-fused":
-        return "step_random_fused_kernel<256, true, false>"
+        return "step_random_fused_kernel<256, true, false, %s>" % ("true" if 0 < int(boards or 0) < 262144 else "false")
     if mode == "random":
         return "step_kernel<%d, %d, false, true, true, false, false>" % (blk, bpl)
     step = "step_kernel<%d, %d, false, true, false, %s, false>" % (blk, bpl, "true" if mode == "gym" else "false")
@@ -429,7 +429,7 @@ def run_legs(torch, dev, args):
         w = Workload(torch, dev, B, K, W, args.seed, 0, mode, fused_T)
         ev, ev_min, _, R = w.measure(no_barrier, ident, target_s=0.02, max_regions=100, **kw)
         us = ev / K * 1e6
-        leg = {"name": name, "boards": B, "mode": mode, "kernel": kernel_label(mode, *w.shape), "steps": K, "warmup": W,
+        leg = {"name": name, "boards": B, "mode": mode, "kernel": kernel_label(mode, *w.shape, boards=B), "steps": K, "warmup": W,
                "regions": R, "us_per_step": us, "best_region_us_per_step": ev_min / K * 1e6, "steps_per_s": B * K / ev,
                "algorithmic_bytes_per_board_step": w.algo_bytes, "achieved_GBps": w.algo_bytes * B / (ev / K) / 1e9,
                "frac": w.algo_bytes * B / (ev / K) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
@@ -507,15 +507,15 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
     return out
 
 
-# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true, false>: 142 761 677 per dispatch of 1 048 576 boards x
-# 64 steps = 8 713.5 per wave = 136.1 per ply (profiles/r05/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own pass;
-# round 4: 148.3); SQ_INSTS_SALU 28.4 executed per wave and ply since the plies' keys travel as a kernel argument
-FUSED_VALU_PER_STEP = 136.1
+# SQ_INSTS_VALU per board-step of step_random_fused_kernel<256, true, false, false>: 139 538 125 per dispatch of 1 048 576
+# boards x 64 steps = 8 516.7 per wave = 133.1 per ply (profiles/r05/pmc_sq_fused_summary.csv; rocprofv3 --pmc, its own
+# pass; round 4: 148.3); SQ_INSTS_SALU 30.4 executed per wave and ply (the plies' keys travel as a kernel argument)
+FUSED_VALU_PER_STEP = 133.1
 # issue time of that instruction mix per wave and ply (tools/isa_budget.py --loop, profiles/r05/isa_budget_random_fused.txt:
-# 65.0 of the 136.1 in the fast class at 1.03 ns per instruction per SIMD, 71.1 in the slow class at 1.75 — a literal
+# 65.0 of the 133.1 in the fast class at 1.03 ns per instruction per SIMD, 68.1 in the slow class at 1.75 — a literal
 # operand does not make a logic instruction slow, an SGPR operand does: profiles/r02/valu_rates.txt): what a SIMD needs
 # per resident wave and ply when it never idles
-FUSED_ISSUE_NS_PER_WAVE_PLY = 191.4
+FUSED_ISSUE_NS_PER_WAVE_PLY = 186.1
 
 
 def config5_leg(torch, dev, args, n=65536, K=50):
@@ -821,7 +821,7 @@ def run(args):
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                              "traffic_source": None if traffic is None else PMC_SUMMARY,
                              "traffic_measured_on_this_build": traffic_fresh,
-                             "kernel": kernel_label(args.mode, bpl, blk), "launch_us": launch_s * 1e6,
+                             "kernel": kernel_label(args.mode, bpl, blk, boards=B), "launch_us": launch_s * 1e6,
                              "algorithmic_bytes_per_board_step": algo_bytes,
                              "algorithmic_bytes_per_launch": algo_bytes * B,
                              # the guide's measured float4-copy rate: what a kernel that moves only its algorithmic
