@@ -359,10 +359,10 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
     hipLaunchKernelGGL((step_fused_kernel<HB, AR>), g, b, 0, s, p.P, p.Q, a16 + (int64_t)done * n,            \
                        bits ? bits + (int64_t)done * n : nullptr, keys, hi_fold, (u32)first,                   \
                        rb + (int64_t)done * out_stride, terminated + (int64_t)done * out_stride, out_stride, n, plies)
-        for (int32_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
-            const int32_t plies = n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES;
+        for (int64_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
+            const int32_t plies = (int32_t)(n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES);
             FusedKeys keys;
-            for (int32_t t = 0; t < FUSED_MAX_PLIES; ++t) keys.k[t] = launch_key(seed, step_idx0 + (u32)(done + (t < plies ? t : 0)));
+            for (int32_t t = 0; t < FUSED_MAX_PLIES; ++t) keys.k[t] = launch_key(seed, step_idx0 + (u32)done + (u32)(t < plies ? t : 0));
             if (bits) { if (ar) QTTT_FUSED(true, true); else QTTT_FUSED(true, false); }
             else      { if (ar) QTTT_FUSED(false, true); else QTTT_FUSED(false, false); }
             const int rc = launch_status();
@@ -405,11 +405,11 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
     // is no faster and at 1 M boards 2 % slower (profiles/r05/fused_keep_instantiation_ab.txt, same box, alternating)
     const bool keep_all = out_stride != 0 && a16 && rb && n < 262144;
 #define QTTT_RF(AR, RT) do { if (keep_all) QTTT_RFK(AR, RT, true); else QTTT_RFK(AR, RT, false); } while (0)
-    for (int32_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
-        const int32_t plies = n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES;
+    for (int64_t done = 0; done < n_steps; done += FUSED_MAX_PLIES) {
+        const int32_t plies = (int32_t)(n_steps - done < FUSED_MAX_PLIES ? n_steps - done : FUSED_MAX_PLIES);
         const bool last = done + plies == n_steps;
         FusedKeys keys;
-        for (int32_t t = 0; t < FUSED_MAX_PLIES; ++t) keys.k[t] = launch_key(seed, step_idx0 + (u32)(done + (t < plies ? t : 0)));
+        for (int32_t t = 0; t < FUSED_MAX_PLIES; ++t) keys.k[t] = launch_key(seed, step_idx0 + (u32)done + (u32)(t < plies ? t : 0));
         const bool writes = out_stride != 0 || last;
         uint16_t *a_c = (a16 && writes) ? a16 + (int64_t)done * out_stride : nullptr;
         u32 *r_c = (rb && writes) ? rb + (int64_t)done * out_stride : nullptr;
