@@ -89,9 +89,11 @@ def parse_args(argv=None):
     ap.add_argument("--regions", type=int, default=0, help="repeat count of the K-step timed region (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for cpu_baseline")
-    ap.add_argument("--mode", choices=["replay", "gym", "policy", "random", "random-fused"], default="replay",
+    ap.add_argument("--mode", choices=["replay", "gym", "gym-default", "policy", "random", "random-fused"], default="replay",
                     help="replay: timed region is env.step only (default, the metric); "
-                         "gym: env.step returning the observation too (step + obs fused in one kernel); "
+                         "gym: env.step returning the observation too (step + obs fused in one kernel), into the "
+                         "environment's own buffers (VecEnv.step_observe_raw, the zero-copy form); "
+                         "gym-default: the same kernel through the DEFAULT VecEnv.step(actions): fresh output tensors every call; "
                          "policy: policy kernel + env.step per step; "
                          "random: policy and env.step fused in one kernel per step; "
                          "random-fused: the same, --fused-steps steps per launch with the boards in registers "
@@ -307,12 +309,13 @@ def kernel_label(mode, bpl, blk, boards=None):
         return "step_random_fused_kernel<256, true, false, %s>" % ("true" if 0 < int(boards or 0) < 262144 else "false")
     if mode == "random":
         return "step_kernel<%d, %d, false, true, true, false, false>" % (blk, bpl)
-    step = "step_kernel<%d, %d, false, true, false, %s, false>" % (blk, bpl, "true" if mode == "gym" else "false")
+    step = "step_kernel<%d, %d, false, true, false, %s, false>" % (blk, bpl, "true" if mode in ("gym", "gym-default") else "false")
     return ("sample_actions_kernel + " + step) if mode == "policy" else step
 
 
 WHAT = {"replay": "recorded actions replayed (env.step only in the timed region)",
-        "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel)",
+        "gym": "recorded actions replayed, env.step returning the observation (step + obs in one kernel) into the environment's own buffers: VecEnv.step_observe_raw",
+        "gym-default": "recorded actions replayed through the default VecEnv.step(actions): (obs, reward, terminated, truncated, info) as fresh tensors every call, one kernel",
         "policy": "policy kernel + env.step per step",
         "random": "policy + env.step fused in one kernel per step",
         "random-fused": "policy + env.step, %d steps per launch with the boards in registers, every step's "
@@ -329,7 +332,7 @@ class Workload:
         T = K + W
         self.env = env = VecEnv(B, device=dev, seed=seed, auto_reset=True, board_offset=board_offset)
         self.state_bytes = int(_native.lib().qttt_state_bytes(64)) // 64
-        gym = mode == "gym"
+        gym = mode in ("gym", "gym-default")
         # algorithmic bytes per board-step: state r+w, action, reward f32, terminated (+ the 30-byte
         # observation of env.py:68-85 in gym mode: classical 9, q_p1 10+1, q_p2 8+1, turn 1).  The fused
         # multi-step form keeps the boards in registers: 7 B of outputs per step + the state once per launch
@@ -370,6 +373,9 @@ class Workload:
         elif mode == "gym":
             for t in range(K):
                 env.step_observe_raw(self.actions[W + t])
+        elif mode == "gym-default":
+            for t in range(K):                                    # a gym loop: the names are rebound every step
+                obs, reward, terminated, truncated, info = env.step(self.actions[W + t])
         elif mode == "policy":
             for t in range(K):
                 env.step_raw(env.sample_actions())
@@ -454,6 +460,7 @@ def run_legs(torch, dev, args):
     step_leg("config3_262144_boards", 262144, "replay", 200, 20)
     step_leg("beyond_infinity_cache_16777216_boards", 16777216, "replay", 10, 2, min_regions=5)
     step_leg("gym_1048576_boards", 1 << 20, "gym", 100, 10)
+    legs.append(gym_default_leg(torch, dev, args))
     step_leg("random_1048576_boards", 1 << 20, "random", 100, 10)
     step_leg("random_fused_1048576_boards", 1 << 20, "random-fused", 128, 10)
     step_leg("random_fused_262144_boards", 262144, "random-fused", 128, 10)
@@ -461,6 +468,34 @@ def run_legs(torch, dev, args):
     legs.append(config5_leg(torch, dev, args))
     legs.extend(row_legs(torch, dev, args))
     return legs
+
+
+def gym_default_leg(torch, dev, args, n=1 << 20, K=100, W=10):
+    """The call BASELINE.json's north_star names — `obs, reward, terminated, truncated, info = env.step(actions)`, the
+    DEFAULT VecEnv.step() (env.py:34-53): fresh output tensors every call, written by the one fused kernel itself.
+    Three clocks, all HIP events on the launch stream: the region clock of every step leg (W launches queued ahead, K
+    timed Python calls: the slower of host and device), the same calls captured in a hipGraph and replayed
+    (device-paced: the kernel's own rate), and K eager calls onto an idle stream."""
+    w = Workload(torch, dev, n, K, W, args.seed, 0, "gym-default", 64)
+    ev, ev_min, _, R = w.measure(lambda: None, float, target_s=0.02, max_regions=100)
+    us = ev / K * 1e6
+    env, a = w.env, w.actions[W]
+    dev_paced, eager = time_calls(torch, dev, lambda: env.step(a), 50, 8)
+    dp = median(dev_paced)
+    leg = {"name": "gym_default_1048576_boards", "boards": n, "mode": "gym-default", "kernel": kernel_label("gym-default", *w.shape, boards=n),
+           "call": "VecEnv.step(actions) -> (obs, reward, terminated, truncated, info), fresh tensors every call (copy_obs=True, the default)",
+           "steps": K, "warmup": W, "regions": R,
+           "us_per_step": us, "best_region_us_per_step": ev_min / K * 1e6,
+           "device_paced_us_per_step": dp, "us_per_python_call_idle_stream": median(eager),
+           "timing": "us_per_step: region clock (W launches queued ahead of K timed Python calls); device_paced: hipGraph of %d "
+                     "default step() calls replayed; us_per_python_call_idle_stream: K eager calls, events around them" % GRAPH_LAUNCHES,
+           "steps_per_s": n * K / ev, "output_sets_in_use": len(env._pool),
+           "algorithmic_bytes_per_board_step": w.algo_bytes, "achieved_GBps": w.algo_bytes * n / (dp * 1e-6) / 1e9,
+           "frac": w.algo_bytes * n / (dp * 1e-6) / 1e9 / HBM_PEAK_GBS, "frac_region_clock": w.algo_bytes * n / (ev / K) / 1e9 / HBM_PEAK_GBS,
+           "bound": "hbm", "replay_matches_recording": w.replay_ok}
+    del w
+    torch.cuda.empty_cache()
+    return leg
 
 
 def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
@@ -785,7 +820,7 @@ def run(args):
             value = total * K / ev_med
             achieved = algo_bytes * B / launch_s / 1e9
             bpl, blk = wl.shape                                            # the library's own choice for this batch
-            gym = args.mode == "gym"
+            gym = args.mode in ("gym", "gym-default")
             traffic, traffic_fresh = (pmc_traffic_per_launch(B, state_bytes) if args.mode == "replay" else
                                       pmc_traffic_per_launch(B, state_bytes, "+gym") if gym else (None, None))
             what = WHAT[args.mode] % args.fused_steps if args.mode == "random-fused" else WHAT[args.mode]
@@ -863,6 +898,9 @@ def run(args):
                     "config2_us": g("config2_4096_boards", "us_per_step"), "config2_frac": g("config2_4096_boards", "frac"),
                     "config3_us": g("config3_262144_boards", "us_per_step"), "config3_frac": g("config3_262144_boards", "frac"),
                     "config3_fused_us": g("random_fused_262144_boards", "us_per_step"),
+                    "gym_us": g("gym_1048576_boards", "us_per_step"),
+                    "gym_default_us": g("gym_default_1048576_boards", "device_paced_us_per_step"),
+                    "gym_default_eager_us": g("gym_default_1048576_boards", "us_per_step"),
                     "config5_us": g("config5_expand_rollout_65536_pairs", "us_per_unit"),
                     "config5_frac": g("config5_expand_rollout_65536_pairs", "frac"),
                     "beyond_cache_us": g("beyond_infinity_cache_16777216_boards", "us_per_step"),

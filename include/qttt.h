@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define QTTT_ABI_VERSION 4
+#define QTTT_ABI_VERSION 5
 
 #define QTTT_ERR_NULL   (-1)
 #define QTTT_ERR_SIZE   (-2)
@@ -56,6 +56,12 @@ int64_t qttt_state_bytes(int64_t n);
 
 /* Env.reset / Env.__init__ (env.py:55-57, 16-32) -> Board.__init__ (board.py:2-7), n boards */
 int qttt_reset(void *state, int64_t n, void *stream);
+
+/* Env.reset INCLUDING the observation it returns (env.py:55-57 -> env.py:68-85 of the empty board), one launch:
+ * qttt_reset followed by qttt_observe (classical all -1, q_p1 / q_p2 all 255 with length 0, turn 0).  Buffers as
+ * qttt_observe; no alignment is required of them. */
+int qttt_reset_observe(void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len, uint8_t *q_p2,
+                       uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream);
 
 /* Env.step (env.py:34-53) for n boards = Board.make_move (board.py:9-25) +
  * Board.update_qstructs (board.py:27-69) + QEvalClassic.eval (qeval.py:5-51) +
@@ -160,13 +166,27 @@ int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, voi
  * either way.  For n > 256 the call does not poll at all: it synchronises the stream, and byte 63 is neither cleared nor
  * stamped (whatever the caller left there stays).  records_out MUST be dereferenceable by the host.
  * n == 1 goes through a BOUNDED MAILBOX instead of a launch: one resident wave on a private non-blocking stream serves a
- * pinned request slot (record copied in, request number written last, answer polled) — Env.step 10.8 us / Board.make_move
- * 7.1 us per call against 17.8 / 12.4 through a launch (profiles/r05/facade_latency*.json; the reference's own Env.step,
- * env.py:34-53, takes ~12 us).  The wave leaves BY ITSELF after QTTT_BOARD_MAILBOX_US microseconds without a request
- * (default 100, capped at 200; 0 disables the mailbox) and is launched again by the next call; a DEVICE-wide synchronise
- * issued inside that window waits for it to leave, stream-level synchronisation does not.  `stream` is not used on this
- * path (host records have no device-side producer to be ordered after); results are identical on both paths. */
+ * pinned request slot — the record travels as FOUR 16-byte pieces of 12 data bytes + the request number each, the numbers
+ * written last, and the wave takes a request only when all four pieces carry the wanted number (the only assumption: one
+ * aligned 16-byte device read of pinned host memory is served from one moment of that memory; x86 keeps the host's
+ * stores in program order); the answer is polled.  Per call, same box (profiles/r06/facade_latency.json): see DESIGN.md §4;
+ * the interpreter running the reference's own Env.step (env.py:34-53) is FASTER than either path on the same host.
+ * The wave leaves BY ITSELF after QTTT_BOARD_MAILBOX_US microseconds without a request (default 20, capped at 200; 0
+ * disables the mailbox), QTTT_BOARD_MAILBOX_MAX_US after it started whatever the traffic (default 1000, capped at 10000:
+ * a thread that keeps calling cannot keep it resident), or when qttt_board_mailbox_retire() asks it to, and is launched
+ * again by the next call; a DEVICE-wide synchronise issued while it is resident waits for it to leave (<= the idle
+ * window after the last call; <= the residency bound when another thread keeps calling), stream-level synchronisation
+ * does not.  `stream` is not used on this path (host records have no device-side producer to be ordered after); results
+ * are identical on both paths. */
 int qttt_board_op_host(const void *records_in, void *records_out, int64_t n, void *stream);
+/* Asks the mailbox wave of qttt_board_op_host to leave NOW (the host writes a "leave" request into the slot; the wave
+ * exits at its next poll, a few microseconds; a no-op when none is resident — one relaxed atomic load).  wait != 0: returns
+ * once the wave has said it left (bounded: 2 ms), so that a device-wide synchronise issued next has nothing of this
+ * library to wait for.  The next single-record call simply launches the wave again.  The step entries (qttt_step,
+ * _observe, _random, _many, _random_many, qttt_env_step) call it themselves (wait = 0) for batches of >= 512 K boards:
+ * a launch that fills the chip would otherwise run a second partial round beside the resident wave (+1.4 us at 1 M
+ * boards).  For a caller that mixes a real Board with batched search, as strat_eval.py:34-63 does. */
+int qttt_board_mailbox_retire(int wait);
 
 /* Synthetic policy for measurement: uniform over legal unordered pairs
  * (GameState.actions rule, mcts.py:20-27) in ind2move order (mcts.py:339-343), index and

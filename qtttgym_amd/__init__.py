@@ -6,6 +6,7 @@ from .vec_env import VecEnv
 from .board import Board, QEvalClassic, displayBoard
 from .env import Env
 from .actions import ind2move, move2ind
-from ._native import recommended_env
+from ._native import recommended_env, retire_mailbox
 
-__all__ = ["Board", "QEvalClassic", "displayBoard", "Env", "VecEnv", "ind2move", "move2ind", "recommended_env"]
+__all__ = ["Board", "QEvalClassic", "displayBoard", "Env", "VecEnv", "ind2move", "move2ind", "recommended_env",
+           "retire_mailbox"]

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # QTTT_LIB_PATH: load another build of the same ABI (A/B diagnostics); default = the in-tree build
 LIB_PATH = os.environ.get("QTTT_LIB_PATH") or os.path.join(_HERE, "libqttt_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_AUTO_RESET = 1
 FLAG_FUSED = 2
 BOARD_RECORD_BYTES = 64
@@ -33,6 +33,7 @@ SIGNATURES = {
     "qttt_abi_version": (_i32, []),
     "qttt_state_bytes": (_i64, [_i64]),
     "qttt_reset": (_i32, [_vp, _i64, _vp]),
+    "qttt_reset_observe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_step": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _i64, _vp]),
     "qttt_step_observe": (_i32, [_vp, _vp, _vp, _u64, _u32, _i64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i64, _vp]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "qttt_board_op": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_board_op_sync": (_i32, [_vp, _vp, _i64, _vp]),
     "qttt_board_op_host": (_i32, [_vp, _vp, _i64, _vp]),
+    "qttt_board_mailbox_retire": (_i32, [_i32]),
     "qttt_sample_actions": (_i32, [_vp, _u64, _u32, _i64, _u32, _vp, _i64, _vp]),
     "qttt_node_info": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qttt_state_key": (_u64, [_u64, _u64]),
@@ -104,6 +106,13 @@ def step_launch_shape(n, flags=0, observe=False):
 
 class QtttNativeError(RuntimeError):
     pass
+
+
+def retire_mailbox(wait=True):
+    """include/qttt.h qttt_board_mailbox_retire: asks the resident wave behind the single-board façades (Board.make_move,
+    Env.step) to leave now — before a device-wide synchronise, or before handing the GPU to something else.  A no-op when
+    none is resident; the next Board / Env call launches it again."""
+    check(lib().qttt_board_mailbox_retire(1 if wait else 0), "qttt_board_mailbox_retire")
 
 
 def lib():

@@ -32,6 +32,25 @@ static long small_int(PyObject *o) {
     return v;
 }
 
+/* a set of squares -> its 9-bit mask (public iteration API only: PyObject_GetIter / PyIter_Next).  0 ok / DECLINE */
+static int set_mask(PyObject *s, unsigned *mask_out) {
+    unsigned mask = 0;
+    if (PySet_GET_SIZE(s) > 9) return DECLINE;        /* not a set of squares: the Python path reports it */
+    PyObject *it = PyObject_GetIter(s);
+    if (!it) { PyErr_Clear(); return DECLINE; }
+    PyObject *key;
+    while ((key = PyIter_Next(it)) != NULL) {
+        long x = small_int(key);
+        Py_DECREF(key);
+        if (x < 0) { Py_DECREF(it); return DECLINE; }  /* (a negative square: the Python path raises what Python raises) */
+        if (x < 16) mask |= 1u << x;
+    }
+    Py_DECREF(it);
+    if (PyErr_Occurred()) { PyErr_Clear(); return DECLINE; }
+    *mask_out = mask;
+    return 0;
+}
+
 /* board's attributes + the move -> the first 41 bytes of the in record (board.py: _Staging.pack).  0 ok / DECLINE */
 static int pack(PyObject *board, int op, int lo, int hi, int bit, int drop_last, PyObject **moves_o, PyObject **board_o,
                 PyObject **qs_o) {
@@ -75,14 +94,7 @@ static int pack(PyObject *board, int op, int lo, int hi, int bit, int drop_last,
         PyObject *s = PyList_GET_ITEM(qs, k);
         if (!PyAnySet_CheckExact(s)) goto done;
         unsigned mask = 0;
-        Py_ssize_t pos = 0;
-        PyObject *key;
-        Py_hash_t h;
-        while (_PySet_NextEntry(s, &pos, &key, &h)) {
-            long x = small_int(key);
-            if (x < 0) goto done;                      /* (a negative square: the Python path raises what Python raises) */
-            if (x < 16) mask |= 1u << x;
-        }
+        if (set_mask(s, &mask) != 0) goto done;
         rec[30 + 2 * k] = (uint8_t)(mask & 255);
         rec[31 + 2 * k] = (uint8_t)(mask >> 8);
     }

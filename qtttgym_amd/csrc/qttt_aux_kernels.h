@@ -551,39 +551,62 @@ __global__ __launch_bounds__(QTTT_COLD_BLOCK) void board_op_kernel(const uint8_t
 }
 
 // The BOUNDED MAILBOX behind qttt_board_op_host for single records (qttt_kernels.hip: board_mailbox): ONE wave stays
-// resident on a private stream and serves one 64-byte request slot in pinned host memory, so that a call costs a
+// resident on a private stream and serves one request slot in pinned host memory, so that a call costs a
 // doorbell write and a poll instead of a kernel launch (tools/sync_latency: 4.4 - 4.8 us against 7.9 - 8.6 for the
 // same echo through a launch).  It is never left resident: it returns BY ITSELF when no request has come for
-// `idle_ticks` of the constant 100 MHz s_memrealtime counter (<= 200 us; the host relaunches it on demand), after
-// `max_rings` requests, or after `max_polls` polls of one wait — every loop below has those exits, all wave-uniform.
-//   slot_in  : the record, bytes 60..63 = the request number (written LAST by the host: a 64-byte line read that
-//              shows the number shows the record — lanes 0..3 read the line with one 4 x 16-byte load)
-//   slot_out : the answer, bytes 60..63 = the request number, written after the rest is visible system-wide
+// `idle_ticks` of the constant 100 MHz s_memrealtime counter, `resident_ticks` after it started whatever the traffic
+// (checked between requests: a caller that keeps it busy cannot keep it resident — a device-wide synchronise in another
+// thread waits for at most that long), when the host asks it to (MBOX_LEAVE in the request numbers:
+// qttt_board_mailbox_retire), after `max_rings` requests, or after `max_polls` polls of one wait — every loop below has
+// those exits, all wave-uniform.
+//   slot_in  : FOUR 16-byte pieces, piece k = record bytes [12k, 12k + 12) + the 4-byte request number (the 41 input
+//              bytes of a record fit the 48 data bytes).  The host writes the data of every piece, then the four numbers;
+//              lane k reads piece k with ONE 16-byte load, and the request is taken only when ALL FOUR pieces carry the
+//              wanted number.  Nothing here assumes that the four loads are one snapshot of the 64-byte line: a piece
+//              whose number is new holds new data as soon as a single aligned 16-byte read is served from one moment
+//              of the line (the host's stores to the data precede the store of the number in program order: x86 TSO),
+//              and a piece whose number is still old keeps the wave polling.
+//   slot_out : the answer in the record's own layout, bytes 60..63 = the request number, written after the rest is
+//              visible system-wide (__threadfence_system between the two: device -> host posted writes)
 //   exited   : receives `generation` when the kernel leaves (the host then knows it must launch again)
 typedef u32 mbox_u32x4 __attribute__((ext_vector_type(4)));
+constexpr u32 MBOX_LEAVE = 0xFFFFFFFFu;                     // never a request number (mbox_next skips it and 0)
+__host__ __device__ __forceinline__ u32 mbox_next(u32 ring) {
+    ++ring;
+    return (ring == 0u || ring == MBOX_LEAVE) ? 1u : ring;
+}
 __global__ __launch_bounds__(64) void board_mailbox_kernel(const mbox_u32x4 *slot_in, mbox_u32x4 *slot_out, u32 *exited,
                                                            u32 generation, u32 first_ring, u32 max_rings, u64 idle_ticks,
-                                                           u32 max_polls) {
+                                                           u32 max_polls, u64 resident_ticks) {
     __shared__ __attribute__((aligned(16))) uint8_t lut[LINE_LUT_BYTES];
     __shared__ __attribute__((aligned(16))) uint8_t rec_in[QTTT_BOARD_RECORD_BYTES], rec_out[QTTT_BOARD_RECORD_BYTES];
     fill_line_lut<64>(lut);
     const u32 lane = threadIdx.x;
+    const u64 t_start = __builtin_amdgcn_s_memrealtime();
+    if (lane < 16) reinterpret_cast<u32 *>(rec_in)[lane] = 0u;                  // bytes 48..63 are never sent
     u32 want = first_ring;
     for (u32 served = 0; served < max_rings; ++served) {
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        if (t0 - t_start > resident_ticks) break;                               // between two requests: none is taken
         bool rung = false;
         mbox_u32x4 v = {0u, 0u, 0u, 0u};
         for (u32 polls = 0; !rung; ++polls) {
-            // system-coherent 16-byte loads (sc0 sc1: past the GPU's caches), one 64-byte line for lanes 0..3
+            // system-coherent 16-byte loads (sc0 sc1: past the GPU's caches), piece k for lane k
             const mbox_u32x4 *src = slot_in + (lane & 3u);
             asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
-            rung = __builtin_amdgcn_readlane(v.w, 3) == want;                   // wave-uniform: lane 3 holds bytes 48..63
-            if (!rung && (polls >= max_polls || __builtin_amdgcn_s_memrealtime() - t0 > idle_ticks)) {
+            const u32 n0 = __builtin_amdgcn_readlane(v.w, 0), n1 = __builtin_amdgcn_readlane(v.w, 1);
+            const u32 n2 = __builtin_amdgcn_readlane(v.w, 2), n3 = __builtin_amdgcn_readlane(v.w, 3);
+            rung = n0 == want && n1 == want && n2 == want && n3 == want;        // wave-uniform
+            const u64 now = __builtin_amdgcn_s_memrealtime();
+            if (!rung && (n3 == MBOX_LEAVE || polls >= max_polls || now - t0 > idle_ticks || now - t_start > resident_ticks)) {
                 if (lane == 0) __hip_atomic_store(exited, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
         }
-        if (lane < 4) reinterpret_cast<mbox_u32x4 *>(rec_in)[lane] = v;
+        if (lane < 4) {
+            u32 *dst = reinterpret_cast<u32 *>(rec_in) + 3u * lane;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -597,7 +620,7 @@ __global__ __launch_bounds__(64) void board_mailbox_kernel(const mbox_u32x4 *slo
         if (lane < 4) slot_out[lane] = reinterpret_cast<const mbox_u32x4 *>(rec_out)[lane];   // the record, number still 0
         __threadfence_system();
         if (lane == 0) __hip_atomic_store(reinterpret_cast<u32 *>(slot_out) + 15, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        ++want;
+        want = mbox_next(want);
     }
     if (lane == 0) __hip_atomic_store(exited, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

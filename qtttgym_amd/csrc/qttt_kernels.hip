@@ -120,6 +120,19 @@ inline int launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// A hint: the single-record mailbox wave (board_mailbox, below) MAY be resident.  It holds one wave slot of one CU, so a
+// launch that fills the chip exactly runs a second partial round beside it (+1.4 us at 1 M boards,
+// profiles/r05/keepwarm_probe.txt): such launches ask it to leave first (it is gone within one poll, before the
+// launch's workgroups are placed).  One relaxed load when no wave is resident.
+std::atomic<bool> g_mailbox_resident{false};
+constexpr int64_t CHIP_FILLING_BOARDS = 512 * 1024;
+inline void retire_mailbox_for(int64_t n) {
+    if (n >= CHIP_FILLING_BOARDS && g_mailbox_resident.load(std::memory_order_relaxed)) {
+        static const bool keep = [] { const char *e = getenv("QTTT_BOARD_MAILBOX_KEEP"); return e && atoi(e) != 0; }();
+        if (!keep) (void)qttt_board_mailbox_retire(0);       // (QTTT_BOARD_MAILBOX_KEEP=1: A/B diagnostics of this very rule)
+    }
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -168,6 +181,51 @@ __global__ __launch_bounds__(256) void reset_kernel(u32x4 *state, int64_t n16) {
 }  // namespace
 extern "C" {
 
+// Env.reset INCLUDING the observation it returns (env.py:55-57,68-85): the empty board's observation is constant
+// (classical -1, no quantum states: 255 pad and length 0, turn 0), so state and observation are seven byte fills in
+// one launch: blockIdx.y = which buffer, 16-byte non-temporal stores, the unaligned head / tail of a caller's odd
+// pointer bytewise.
+namespace {
+struct FillSegs {
+    uint8_t *p[7];
+    int64_t bytes[7];
+    u32 word[7];                                             // the fill byte, four times
+};
+__global__ __launch_bounds__(256) void reset_observe_kernel(FillSegs f) {
+    const u32 seg = blockIdx.y;
+    uint8_t *p = f.p[seg];
+    const int64_t nb = f.bytes[seg];
+    const u32 w = f.word[seg];
+    int64_t head = (int64_t)((16u - (u32)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u);
+    if (head > nb) head = nb;
+    const int64_t nvec = (nb - head) >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nvec) __builtin_nontemporal_store(u32x4{w, w, w, w}, reinterpret_cast<u32x4 *>(p + head) + i);
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int64_t k = threadIdx.x & 15;
+        if (threadIdx.x < 16) { if (k < head) p[k] = (uint8_t)w; }
+        else { const int64_t off = head + (nvec << 4) + k; if (off < nb) p[off] = (uint8_t)w; }
+    }
+}
+}  // namespace
+
+int qttt_reset_observe(void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q_p1_len, uint8_t *q_p2,
+                       uint8_t *q_p2_len, uint8_t *turn, int64_t n, void *stream) {
+    if (n < 0) return QTTT_ERR_SIZE;
+    if (n == 0) return 0;
+    if (!state || !classical || !q_p1 || !q_p1_len || !q_p2 || !q_p2_len || !turn) return QTTT_ERR_NULL;
+    FillSegs f;
+    const int64_t sb = plane_stride(n) * QTTT_STATE_BYTES;
+    uint8_t *ptrs[7] = {static_cast<uint8_t *>(state), reinterpret_cast<uint8_t *>(classical), q_p1, q_p1_len, q_p2, q_p2_len, turn};
+    const int64_t bytes[7] = {sb, 9 * n, 10 * n, n, 8 * n, n, n};
+    const u32 words[7] = {0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u, 0u};
+    int64_t most = 0;
+    for (int k = 0; k < 7; ++k) { f.p[k] = ptrs[k]; f.bytes[k] = bytes[k]; f.word[k] = words[k]; if (bytes[k] > most) most = bytes[k]; }
+    const unsigned gx = (unsigned)(((most >> 4) + 255) / 256);
+    hipLaunchKernelGGL(reset_observe_kernel, dim3(gx ? gx : 1u, 7u), dim3(256), 0, (hipStream_t)stream, f);
+    return launch_status();
+}
+
 int qttt_reset(void *state, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;
     if (n == 0) return 0;
@@ -191,6 +249,7 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     if (n == 0) return 0;
     if (!state || !reward || !terminated || (!sample && !actions)) return QTTT_ERR_NULL;
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are accessed as u16 pairs
+    retire_mailbox_for(n);
     Planes p = planes(state, n);
     // with a device-side step counter the kernel makes the key itself: it gets the offset and the id fold
     const u64 key = step_ctr ? ((u64)step_idx << 32) : launch_key(seed, step_idx);
@@ -346,6 +405,7 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
         if (board_offset < 0) return QTTT_ERR_SIZE;
         if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
         if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;
+        retire_mailbox_for(n);
         Planes p = planes(state, n);
         const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
         const u32 hi_fold = (u32)(first >> 32) * 0x9E3779B9u;
@@ -388,6 +448,7 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
     if (n == 0 || n_steps == 0) return 0;
     if (!state || (reward == nullptr) != (terminated == nullptr)) return QTTT_ERR_NULL;
     if (((uintptr_t)actions_out & 1u) || ((uintptr_t)reward & 3u) || ((uintptr_t)returns & 3u)) return QTTT_ERR_ACTION;
+    retire_mailbox_for(n);
     Planes p = planes(state, n);
     hipStream_t s = (hipStream_t)stream;
     uint16_t *a16 = reinterpret_cast<uint16_t *>(actions_out);
@@ -515,34 +576,42 @@ int qttt_board_op_sync(const void *records_in, void *records_out, int64_t n, voi
 // ~2 ms (or a batch too large to poll) falls back to synchronising the stream, so the call always returns.
 // ---- the bounded mailbox for SINGLE records (board_mailbox_kernel, qttt_aux_kernels.h) ----
 // One resident wave on a private non-blocking stream serves a pinned request slot; a call is: copy the record into the
-// slot, write the request number (last), poll the answer's number.  The wave leaves by itself after QTTT_BOARD_MAILBOX_US
-// microseconds without a request (default 100, at most 200; 0 = no mailbox: every call is a launch, as before round 5),
-// and says so in `exited`; the next call then launches it again.  A request that meets a wave which has just left is
-// answered by the relaunch (the host watches `exited` while it polls), and a call that gets no answer within 20 ms
-// turns the mailbox off for the rest of the process and goes through the launch path — the call always returns.
+// slot (four 16-byte pieces of 12 data bytes + the request number each; the numbers are written last), poll the
+// answer's number.  The wave leaves by itself after QTTT_BOARD_MAILBOX_US microseconds without a request (default 20,
+// at most 200; 0 = no mailbox: every call is a launch, as before round 5), QTTT_BOARD_MAILBOX_MAX_US after it started
+// whatever the traffic (default 1000, at most 10000), or when qttt_board_mailbox_retire() asks it to, and says so in
+// `exited`; the next call then launches it again.  A request that meets a wave which has just left is answered by the
+// relaunch (the host watches `exited` while it polls), and a call that gets no answer within 20 ms turns the mailbox
+// off for the rest of the process and goes through the launch path — the call always returns.
 // What a resident wave costs others: a DEVICE-wide synchronise (hipDeviceSynchronize, torch.cuda.synchronize()) issued
-// within the idle window after a Board call waits for the wave to leave (<= the window); stream-level synchronisation
-// and the legacy default stream do not (the stream is non-blocking).  The `stream` argument of the call is not used on
-// this path: host records have no device-side producer to be ordered after.
+// within the idle window after a Board call waits for the wave to leave (<= the window; <= the residency bound when
+// another thread keeps calling); stream-level synchronisation and the legacy default stream do not (the stream is
+// non-blocking).  A step launch that fills the chip (>= 512 K boards) retires it first (launch_step), so that the wave's
+// CU slot does not cost that launch a second partial round.  The `stream` argument of the call is not used on this path:
+// host records have no device-side producer to be ordered after.
 }  // extern "C"
 namespace {
 struct BoardMailbox {
     std::mutex mu;
-    bool tried = false, on = false, alive = false;
+    bool tried = false, on = false, alive = false, leaving = false;
     int device = -1;
     uint8_t *slot_in = nullptr, *slot_out = nullptr;     // 64 bytes each, pinned, system-coherent
     u32 *exited = nullptr;
     hipStream_t stream = nullptr;
     u32 ring = 0, generation = 0;
-    u64 idle_ticks = 0;
+    u64 idle_ticks = 0, resident_ticks = 0;
 
     bool start() {                                       // once per process
         tried = true;
-        long us = 100;
+        long us = 20, max_us = 1000;
         if (const char *e = getenv("QTTT_BOARD_MAILBOX_US")) us = atol(e);
+        if (const char *e = getenv("QTTT_BOARD_MAILBOX_MAX_US")) max_us = atol(e);
         if (us <= 0) return false;
         if (us > 200) us = 200;
+        if (max_us < us) max_us = us;
+        if (max_us > 10000) max_us = 10000;
         idle_ticks = (u64)us * 100u;                     // s_memrealtime: 100 MHz
+        resident_ticks = (u64)max_us * 100u;
         uint8_t *mem = nullptr;
         if (hipGetDevice(&device) != hipSuccess) return false;
         if (hipHostMalloc(reinterpret_cast<void **>(&mem), 256, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -555,9 +624,38 @@ struct BoardMailbox {
     bool launch() {
         ++generation;
         hipLaunchKernelGGL(board_mailbox_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const mbox_u32x4 *>(slot_in),
-                           reinterpret_cast<mbox_u32x4 *>(slot_out), exited, generation, ring, 1u << 20, idle_ticks, 1u << 20);
+                           reinterpret_cast<mbox_u32x4 *>(slot_out), exited, generation, ring, 1u << 20, idle_ticks, 1u << 20,
+                           resident_ticks);
         alive = hipGetLastError() == hipSuccess;
+        leaving = false;
+        g_mailbox_resident.store(alive, std::memory_order_relaxed);
         return alive;
+    }
+    void write_numbers(u32 v) {
+        volatile u32 *w = reinterpret_cast<volatile u32 *>(slot_in);
+        w[3] = v; w[7] = v; w[11] = v; w[15] = v;
+    }
+    // the wave was asked to leave: wait until it has said so (its next poll: a few us; bounded)
+    void await_exit() {
+        volatile u32 *gone = exited;
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        for (unsigned spin = 1; *gone != generation; ++spin)
+            if ((spin & 1023u) == 0u && std::chrono::steady_clock::now() > give_up) break;   // (it then leaves by its idle exit)
+        alive = leaving = false;
+    }
+    // 0 = a resident wave was asked to leave (or none was resident); it is gone within a poll (a few us)
+    int retire(bool wait) {
+        std::lock_guard<std::mutex> g(mu);
+        g_mailbox_resident.store(false, std::memory_order_relaxed);
+        if (!on || !alive) return 0;
+        volatile u32 *gone = exited;
+        if (*gone == generation) { alive = leaving = false; return 0; }
+        if (!leaving) {
+            write_numbers(MBOX_LEAVE);
+            leaving = true;
+        }
+        if (wait) await_exit();
+        return 0;
     }
     // 0 = answered (out filled), 1 = not served: use the launch path
     int call(const void *rec_in, void *rec_out) {
@@ -565,14 +663,15 @@ struct BoardMailbox {
         if (!tried) start();
         int dev = -1;
         if (!on || hipGetDevice(&dev) != hipSuccess || dev != device) return 1;
-        ++ring;
-        if (ring == 0u) ring = 1u;                       // 0 is "no request"
+        if (leaving) await_exit();
+        ring = mbox_next(ring);
         volatile u32 *answer = reinterpret_cast<volatile u32 *>(slot_out) + 15;
         volatile u32 *gone = exited;
         if (alive && *gone == generation) alive = false;
-        memcpy(slot_in, rec_in, 60);
+        const uint8_t *src = static_cast<const uint8_t *>(rec_in);
+        for (int k = 0; k < 4; ++k) memcpy(slot_in + 16 * k, src + 12 * k, 12);   // record bytes 0..47 (41 are read)
         std::atomic_thread_fence(std::memory_order_release);
-        *(reinterpret_cast<volatile u32 *>(slot_in) + 15) = ring;
+        write_numbers(ring);
         if (!alive && !launch()) { on = false; return 1; }
         const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
         for (unsigned spin = 1; *answer != ring; ++spin) {
@@ -597,6 +696,11 @@ BoardMailbox &board_mailbox() {
 }
 }  // namespace
 extern "C" {
+
+int qttt_board_mailbox_retire(int wait) {
+    if (!g_mailbox_resident.load(std::memory_order_relaxed) && !wait) return 0;
+    return board_mailbox().retire(wait != 0);
+}
 
 int qttt_board_op_host(const void *records_in, void *records_out, int64_t n, void *stream) {
     if (n < 0) return QTTT_ERR_SIZE;

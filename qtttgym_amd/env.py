@@ -1,13 +1,17 @@
 """`Env` — the reference's single-board gymnasium-style surface (qtttgym/env.py:15-112),
 returning the same Python types (dict observation with an aliasing `classical` list, float
 reward incl. -0.0, bool terminated, False, {}), with the rules running in the HIP kernel via
-the `Board` façade.  For N boards per call use `VecEnv`."""
+the `Board` façade.  For N boards per call use `VecEnv`.
+
+As in the reference (env.py:5-8,15) `Env` IS a `gymnasium.Env` with real gymnasium spaces whenever gymnasium is
+importable (spaces.py); without it — the target image has none — it is a plain class with the declarative stand-ins."""
 from .board import Board, QEvalClassic, displayBoard
-from .spaces import reference_action_space, reference_observation_space
+from .spaces import GYM_ENV_BASE, reference_action_space, reference_observation_space
 
 
-class Env:
+class Env(GYM_ENV_BASE):
     def __init__(self):
+        super().__init__()                                        # env.py:17
         self.action_space = reference_action_space()              # env.py:19
         self.observation_space = reference_observation_space()    # env.py:20-25
         self._gameboard = Board(QEvalClassic())                   # env.py:26

@@ -6,6 +6,7 @@ All arithmetic happens in libqttt_hip.so (include/qttt.h); torch is used for dev
 and streams only.
 """
 import ctypes
+import sys
 
 import torch
 
@@ -23,6 +24,66 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
+_is_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None) or torch.cuda.is_current_stream_capturing
+_OBS_KEYS = ("q_states_p1", "q_states_p1_len", "q_states_p2", "q_states_p2_len", "classical", "turn")
+
+
+class _OutputSet:
+    """What ONE default step() / reset() returns — reward f32[N], terminated bool[N] and the six observation tensors
+    (env.py:46,53,68-85) — as views of ONE allocation from torch's caching allocator (each view starts on a 512-byte
+    boundary), plus the qttt_env record that points the step kernel at them: the kernel writes the caller's fresh
+    tensors directly, nothing is copied afterwards.
+
+    A set is handed out again only when nothing outside the environment can still see it, which `free()` checks
+    exactly: no Python reference to any of its eight tensors beyond the environment's own (sys.getrefcount), no C++
+    reference to their TensorImpls (autograd, DLPack: Tensor._use_count) and no other tensor on their storage (views,
+    .detach(), .data: the storage's use count).  A caller that rebinds `obs, reward, terminated, ... = env.step(a)`
+    every step therefore alternates between two sets with no allocation and no view construction per step; a caller
+    that keeps every observation gets a new allocation every step.  Either way the tensors of step t are never
+    written again while the caller can reach them."""
+    __slots__ = ("t", "rec", "rec_ref", "stream", "_st", "_base")
+
+    def __init__(self, env):
+        n, dev = env.num_envs, env.device
+        seg = lambda nbytes: (nbytes + 511) // 512 * 512
+        sizes = (4 * n, n, 10 * n, n, 8 * n, n, 9 * n, n)      # reward, terminated, then the _OBS_KEYS order
+        offs, total = [], 0
+        for b in sizes:
+            offs.append(total)
+            total += seg(b)
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        cut = lambda k, shape, stride: torch.as_strided(buf, shape, stride, offs[k])
+        self.t = (cut(0, (4 * n,), (1,)).view(torch.float32), cut(1, (n,), (1,)).view(torch.bool),
+                  cut(2, (n, 5, 2), (10, 2, 1)), cut(3, (n,), (1,)), cut(4, (n, 4, 2), (8, 2, 1)), cut(5, (n,), (1,)),
+                  cut(6, (n, 9), (9, 1)).view(torch.int8), cut(7, (n,), (1,)))
+        base = buf.data_ptr()
+        p = [base + o for o in offs]
+        self.rec = _native.EnvRecord(n=n, reward=p[0], terminated=p[1], q_p1=p[2], q_p1_len=p[3], q_p2=p[4],
+                                     q_p2_len=p[5], classical=p[6], turn=p[7])
+        self.rec_ref = ctypes.byref(self.rec)
+        self.stream = None
+        self._st = buf.untyped_storage() if _storage_use_count is not None else None
+        del buf, cut
+        self._base = self._probe()
+
+    def _probe(self):
+        rc, m = sys.getrefcount, 0
+        for t in self.t:
+            c = rc(t) + (t._use_count() << 20)
+            if c > m:
+                m = c
+        return m, _storage_use_count(self._st._cdata)
+
+    def free(self):
+        return self._st is not None and self._probe() == self._base
+
+    def obs(self):
+        t = self.t
+        return {"q_states_p1": t[2], "q_states_p1_len": t[3], "q_states_p2": t[4], "q_states_p2_len": t[5],
+                "classical": t[6], "turn": t[7]}
+
+
 def _check_out(t, dtype, shape, dev, what):
     if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != dev:
         raise ValueError("%s must be a contiguous %s device tensor of shape %s" % (what, dtype, tuple(shape)))
@@ -34,7 +95,8 @@ class VecEnv:
     (its state, its output buffers and its qttt_env record) belongs to one thread at a time, exactly
     like the reference's mutable Env (env.py:15)."""
 
-    def __init__(self, num_envs, device="cuda", seed=0, auto_reset=False, board_offset=0, launch_shape=None):
+    def __init__(self, num_envs, device="cuda", seed=0, auto_reset=False, board_offset=0, launch_shape=None,
+                 output_pool=4):
         self.num_envs = int(num_envs)
         if self.num_envs < 0:
             raise ValueError("num_envs must be >= 0")
@@ -64,8 +126,10 @@ class VecEnv:
             self._terminated = torch.empty(n, dtype=torch.bool, device=self.device)
             self._truncated = torch.zeros(n, dtype=torch.bool, device=self.device)  # env.py:52
         self._obs = None
+        # default step() / reset(): at most this many output sets are kept for re-use (0: a new allocation per call)
+        self._pool, self._pool_i, self._pool_max = [], 0, max(0, int(output_pool))
         self._bind_outputs()
-        self.reset()
+        self.reset_raw()
 
     # ------------------------------------------------------------------ the step index
     @property
@@ -148,6 +212,13 @@ class VecEnv:
             actions = torch.where((a < 0) | (a > 255), torch.full_like(a, 255), a).to(torch.uint8)
         return actions.to(self.device).contiguous()
 
+    def synchronize(self):
+        """torch.cuda.synchronize(device) for a process that also uses the single-board façades (Board, Env): their
+        mailbox wave (include/qttt.h, qttt_board_op_host) is asked to leave first, so the device-wide wait has nothing
+        of this library to wait for (otherwise: up to the wave's idle window, 20 us by default)."""
+        self._lib.qttt_board_mailbox_retire(1)
+        torch.cuda.synchronize(self.device)
+
     # ------------------------------------------------------------------ gym surface
     def reset_raw(self, seed=None):
         """Fresh boards without building the observation (one memset on the stream)."""
@@ -158,14 +229,55 @@ class VecEnv:
             _native.check(self._lib.qttt_reset(self.state.data_ptr(), self.num_envs, self._stream()),
                           "qttt_reset")
 
+    def _fresh_outputs(self):
+        """An output set nobody else can see: a pooled one that is free (see _OutputSet), else a new allocation.
+        Inside a hipGraph capture every call allocates (from the graph's private pool, which lives as long as the
+        graph): a captured launch keeps writing where it was captured, so its buffers must never be handed out again."""
+        stream = self._stream()
+        if self._pool_max and not _is_capturing():
+            pool, i = self._pool, self._pool_i
+            k = len(pool)
+            for _ in range(k):
+                i = i + 1 if i + 1 < k else 0
+                s = pool[i]
+                # (re-use only on the stream that wrote it last: the same rule as torch's caching allocator)
+                if s.stream == stream and s.free():
+                    self._pool_i = i
+                    return s
+            s = _OutputSet(self)
+            s.stream = stream
+            if k < self._pool_max:
+                pool.append(s)
+                self._pool_i = k
+            else:                                   # every set is still held by the caller: forget the oldest one
+                i = self._pool_i + 1 if self._pool_i + 1 < k else 0
+                pool[i] = s
+                self._pool_i = i
+            return s
+        s = _OutputSet(self)
+        s.stream = stream
+        return s
+
     def reset(self, *, seed=None, options=None, copy_obs=True):
-        """env.py:55-57: fresh boards; `seed`/`options` accepted and ignored like the reference,
-        except that an int `seed` re-keys the collapse-bit hash (the reference has no per-env RNG).
-        The observation is a fresh copy unless copy_obs=False (then: the environment's own buffers, which the
-        next step()/observ() overwrites — as for step())."""
-        self.reset_raw(seed)
-        obs = self.observ()
-        return ({k: v.clone() for k, v in obs.items()} if copy_obs else obs), {}
+        """env.py:55-57: fresh boards and their observation, ONE kernel (qttt_reset_observe); `seed`/`options`
+        accepted and ignored like the reference, except that an int `seed` re-keys the collapse-bit hash (the
+        reference has no per-env RNG).  The observation is made of fresh tensors (written by the kernel itself, never
+        copied) unless copy_obs=False (then: the environment's own buffers, which the next copy_obs=False step() /
+        observ() overwrites)."""
+        if seed is not None:
+            self.seed = int(seed)
+        self.step_idx = 0
+        if copy_obs:
+            s = self._fresh_outputs()
+            r, obs = s.rec, s.obs()
+        else:
+            obs = self._obs_buffers()
+            r = self._rec
+        rc = self._launch(self._lib.qttt_reset_observe, self.state.data_ptr(), r.classical, r.q_p1, r.q_p1_len, r.q_p2,
+                          r.q_p2_len, r.turn, self.num_envs, self._stream())
+        if rc:
+            _native.check(rc, "qttt_reset_observe")
+        return obs, {}
 
     def step_raw(self, actions, bits=None):
         """The hot path alone: one fused kernel launch, no observation unpack.
@@ -233,11 +345,13 @@ class VecEnv:
         return r, tm
 
     def step(self, actions, bits=None, verbose=False, copy_obs=True):
-        """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info) from ONE kernel
-        launch (the step kernel writes the observation from the registers it holds).
-        copy_obs=True (default): the returned observation, reward and terminated are fresh tensors, as a
-        gym caller that keeps (obs, next_obs) pairs expects.  copy_obs=False returns the environment's
-        own buffers, overwritten by the next step()/observ() — the zero-copy form, = step_observe_raw."""
+        """env.py:34-53 for N boards: (obs, reward, terminated, truncated, info) from ONE kernel launch and nothing
+        else (the step kernel writes the observation from the registers it holds, straight into the tensors returned).
+        copy_obs=True (default): the returned observation, reward and terminated are tensors nobody else holds — as
+        the reference's Env.step builds new lists every call (env.py:46,68-85), a gym caller may keep (obs, next_obs)
+        pairs, or every observation of an episode; they are never written again while the caller can reach them
+        (_OutputSet).  copy_obs=False returns the environment's own buffers, overwritten by the next such step() /
+        observ() — = step_observe_raw."""
         dev = self.state.device
         if not (torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == dev
                 and actions.shape == (self.num_envs, 2) and actions.is_contiguous()):
@@ -245,11 +359,23 @@ class VecEnv:
         if bits is not None and not (torch.is_tensor(bits) and bits.dtype == torch.uint8 and bits.device == dev
                                      and bits.is_contiguous()):
             bits = torch.as_tensor(bits).to(torch.uint8).to(self.device).contiguous()
-        obs, reward, terminated = self.step_observe_raw(actions, bits)
-        if copy_obs:
-            obs = {k: v.clone() for k, v in obs.items()}
-            reward, terminated = reward.clone(), terminated.clone()
-        return obs, reward, terminated, self._truncated, {}
+        if not copy_obs:
+            obs, reward, terminated = self.step_observe_raw(actions, bits)
+            return obs, reward, terminated, self._truncated, {}
+        if bits is not None and bits.numel() != self.num_envs:
+            raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
+        s = self._fresh_outputs()
+        r, own = s.rec, self._rec
+        r.state = self.state.data_ptr()
+        r.board_offset, r.seed, r.flags, r.step_counter = self.board_offset, self.seed, self._flags(), own.step_counter
+        rc = self._launch(self._env_step, s.rec_ref, actions.data_ptr(), _ptr(bits), self._step_host,
+                          _native.ENV_STEP_OBSERVE, s.stream)
+        if rc:
+            _native.check(rc, "qttt_step_observe")
+        self._advance(1)
+        t = s.t
+        return ({"q_states_p1": t[2], "q_states_p1_len": t[3], "q_states_p2": t[4], "q_states_p2_len": t[5],
+                 "classical": t[6], "turn": t[7]}, t[0], t[1], self._truncated, {})
 
     def _obs_buffers(self):
         """The observation tensors (env.py:19-25,68-85), allocated once per environment."""
@@ -449,6 +575,7 @@ class VecEnv:
             env._terminated = torch.empty(n, dtype=torch.bool, device=env.device)
             env._truncated = torch.zeros(n, dtype=torch.bool, device=env.device)
         env._obs = None
+        env._pool, env._pool_i, env._pool_max = [], 0, 4
         env._bind_outputs()
         return env
 
