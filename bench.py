@@ -181,48 +181,55 @@ def cpu_model():
 
 
 def cpu_baseline(actions_host, seed, budget_s):
-    """Times the CPU oracle (oracle/qttt_oracle.c, a scalar C port of the reference algorithm)
-    on this box's host cores, on a bounded sample of the same workload: the recorded steps of a
-    slice of the boards, one slice per thread, replayed (reset + replay) until the budget of wall
-    time has been spent on every thread.  Two passes: ONE thread (a quarter of the budget, `threads1`)
-    and all the threads of this GPU's CPU share (`value`, `cores`); SURVEY.md §8(d) asks for both,
-    with the box's nproc and CPU model beside them."""
+    """Times the CPU oracle (oracle/qttt_oracle.c, a scalar C port of the reference algorithm) on this box's host
+    cores, on a bounded sample of the same workload: the recorded steps of a slice of the boards, one slice per thread,
+    replayed (reset + replay, one C call per replay: qo_replay_batch) until the pass's share of the budget of wall time
+    has been spent on every thread.  Three passes, as SURVEY.md §8(d) asks ("1 thread and all host cores", with the
+    box's nproc and CPU model beside them): ONE thread (`threads1`), the threads of this GPU's CPU share (`value`,
+    `cores` — a one-GPU box of the pool gives a job 16 of the host's cores), and ALL the host's hardware threads
+    (`threads_all`, `threads_all_cores` = os.cpu_count())."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     import oracle
+    actions_host = np.ascontiguousarray(actions_host)
     T, n = actions_host.shape[0], actions_host.shape[1]
     nproc = os.cpu_count() or 1
-    cores = max(1, min(nproc, 16))                 # the GPU box's CPU share for one GPU
-    per = n // cores
-    slices = [np.ascontiguousarray(actions_host[:, k * per:(k + 1) * per]) for k in range(cores)]
+    share = max(1, min(nproc, 16))                 # the GPU box's CPU share for one GPU
+    base = actions_host.ctypes.data
 
-    def work(k, budget):
-        done, passes = 0, 0
-        t_end = time.perf_counter() + budget
-        while True:
-            ob = oracle.OracleBoards(per)            # reset
-            for t in range(T):
-                ob.step(slices[k][t], None, seed, t, k * per, True)
-                done += per
+    def run_pass(threads, budget, per=None):
+        per = per or n // threads
+
+        def work(k):
+            ob = oracle.OracleBoards(per)
+            scratch = (np.empty(per, dtype=np.float32), np.empty(per, dtype=np.uint8))
+            done = 0
+            t_end = time.perf_counter() + budget
+            while True:
+                ob.reset()
+                ob.replay(base + 2 * k * per, n, T, seed, 0, k * per, True, scratch)
+                done += per * T
                 if time.perf_counter() > t_end:
-                    return done, passes
-            passes += 1
-    t0 = time.perf_counter()
-    one = work(0, budget_s * 0.25)
-    dt1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        res = list(ex.map(lambda k: work(k, budget_s), range(cores)))
-    dt = time.perf_counter() - t0
-    total = sum(r[0] for r in res)
+                    return done
+        t0 = time.perf_counter()
+        if threads == 1:
+            total = work(0)
+        else:
+            with ThreadPoolExecutor(threads) as ex:
+                total = sum(ex.map(work, range(threads)))
+        dt = time.perf_counter() - t0
+        return total / dt, dt, per, total
+    v1, dt1, per1, _ = run_pass(1, budget_s * 0.15, per=n // share)     # one of the share pass's slices
+    v, dt, per, total = run_pass(share, budget_s * 0.6)
+    va, dta, pera, _ = (v, dt, per, total) if nproc == share else run_pass(nproc, budget_s * 0.25)
     py = python_interpreter_line(actions_host, seed)
-    return {"value": total / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "threads1": one[0] / dt1, "nproc": nproc, "cpu_model": cpu_model(),
+    return {"value": v, "unit": "steps/s", "cores": share, "kind": "port",
+            "threads1": v1, "threads_all": va, "threads_all_cores": nproc, "nproc": nproc, "cpu_model": cpu_model(),
             "python_interpreter_steps_per_s": py,
             "sample": "%d boards x the first %d recorded steps of the same workload (uniform-legal policy, "
                       "auto-reset), replayed from reset %.1f times, %d threads x %d boards, %.1f s of wall time; "
-                      "threads1: one of those slices on one thread, %.1f s"
-                      % (per * cores, T, total / float(per * cores * T), cores, per, dt, dt1)}
+                      "threads1: one slice of %d boards on one thread, %.1f s; threads_all: %d threads x %d boards, %.1f s"
+                      % (per * share, T, total / float(per * share * T), share, per, dt, per1, dt1, nproc, pera, dta)}
 
 
 def python_interpreter_line(actions_host, seed, budget_s=2.0):
@@ -885,7 +892,7 @@ def run(args):
                                            beyond_cache_frac=big[0]["frac"],
                                            beyond_cache_frac_of_achievable=big[0]["achieved_GBps"] / HBM_ACHIEVABLE_GBS)
             if not args.no_cpu_baseline and world == 1:                 # rank 0 at N = 1 only
-                # bounded sample: the first <=256 recorded steps of every board of rank 0, ~15 s of CPU
+                # bounded sample: the first <=256 recorded steps of every board of rank 0, ~14 s of CPU in all
                 t_cpu = min(K + W, 256)
                 out["cpu_baseline"] = cpu_baseline(actions[:t_cpu].cpu().numpy(), args.seed, args.cpu_budget)
             if "legs" in out:

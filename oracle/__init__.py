@@ -58,6 +58,7 @@ def lib():
         L.qo_observe.argtypes = [vp] * 7
         L.qo_reset_batch.argtypes = [vp, i64]
         L.qo_step_batch.argtypes = [vp, i64, vp, vp, u64, u32, i64, i32, vp, vp]
+        L.qo_replay_batch.argtypes = [vp, i64, vp, i64, i32, u64, u32, i64, i32, vp, vp]
         L.qo_terminated.argtypes = [vp]
         L.qo_terminated.restype = i32
         L.qo_hash.argtypes = [u64, u64, u32]
@@ -111,6 +112,15 @@ class OracleBoards:
         lib().qo_step_batch(_ptr(self.b), self.n, _ptr(actions), bp, int(seed), int(step_idx),
                             int(board_offset), int(bool(auto_reset)), _ptr(reward), _ptr(term))
         return reward, term
+
+    def replay(self, actions_base_ptr, stride, n_steps, seed=0, step_idx0=0, board_offset=0, auto_reset=False, scratch=None):
+        """n_steps steps from a recorded action stream u8[T, stride, 2] whose slice for these boards starts at the
+        address actions_base_ptr (hashed collapse bits): ONE C call, for bench.py's cpu_baseline."""
+        if scratch is None:
+            scratch = (np.empty(self.n, dtype=np.float32), np.empty(self.n, dtype=np.uint8))
+        lib().qo_replay_batch(_ptr(self.b), self.n, ctypes.c_void_p(actions_base_ptr), int(stride), int(n_steps), int(seed),
+                              int(step_idx0), int(board_offset), int(bool(auto_reset)), _ptr(scratch[0]), _ptr(scratch[1]))
+        return scratch
 
     def sample_actions(self, seed, step_idx, board_offset=0, auto_reset=False):
         actions = np.empty((self.n, 2), dtype=np.uint8)

@@ -290,6 +290,18 @@ void qo_step_batch(qo_board *b, int64_t n, const uint8_t *actions, const uint8_t
     }
 }
 
+/* n_steps consecutive qo_step_batch passes over one slice of boards from a recorded action stream
+ * actions[t][stride boards][2] (the slice starts at `actions`; the next step's actions are stride boards on): what
+ * bench.py's cpu_baseline times — one C call per (thread, replay), so that a host with hundreds of threads is not
+ * bound by the interpreter lock between steps.  reward / terminated: n-element scratch, overwritten every step. */
+void qo_replay_batch(qo_board *b, int64_t n, const uint8_t *actions, int64_t stride, int32_t n_steps,
+                     uint64_t seed, uint32_t step_idx0, int64_t board_offset, int auto_reset,
+                     float *reward, uint8_t *terminated) {
+    for (int32_t t = 0; t < n_steps; ++t)
+        qo_step_batch(b, n, actions + (int64_t)t * stride * 2, NULL, seed, step_idx0 + (uint32_t)t, board_offset,
+                      auto_reset, reward, terminated);
+}
+
 /* ================================================================== MCTS expand row */
 void qo_ind2move(int n, int *lo, int *hi) {               /* mcts.py:339-343 */
     /* the reference inverts the triangular numbering with a float sqrt; the table it produces

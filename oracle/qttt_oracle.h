@@ -45,6 +45,9 @@ void qo_reset_batch(qo_board *b, int64_t n);
 void qo_step_batch(qo_board *b, int64_t n, const uint8_t *actions, const uint8_t *bits,
                    uint64_t seed, uint32_t step_idx, int64_t board_offset, int auto_reset,
                    float *reward, uint8_t *terminated);
+void qo_replay_batch(qo_board *b, int64_t n, const uint8_t *actions, int64_t stride, int32_t n_steps,
+                     uint64_t seed, uint32_t step_idx0, int64_t board_offset, int auto_reset,
+                     float *reward, uint8_t *terminated);
 int  qo_terminated(const qo_board *b);                             /* env.py:48,51 */
 
 /* ---- the build's synthetic-input spec, shared with the HIP policy kernel ---- */

@@ -141,112 +141,3 @@ def test_per_rank_bookkeeping_with_eight_gloo_ranks():
     assert gather_rank_values([3, 4]) == [[3.0, 4.0]] and agree(True) is True and agree(False) is False   # no process group
 
 
-def test_fastboard_agrees_with_the_python_bookkeeping():
-    """qtttgym_amd/_fastboard.so (csrc/fastboard.c) against board.py's own pack / _adopt, no GPU: a ctypes callback
-    stands in for qttt_board_op_host, so what is compared is exactly the host bookkeeping — the 41 packed bytes, the
-    attributes afterwards, and WHICH set / list objects survive (the reference's aliasing, board.py:19,25,53-69)."""
-    import ctypes
-    import random
-    sys.path.insert(0, ROOT)
-    import __graft_entry__ as g
-    g.build_fastboard()
-    from qtttgym_amd import _fastboard
-    from qtttgym_amd.board import Board, QEvalClassic, _Staging
-    buf_in = (ctypes.c_uint8 * 64)()
-    buf_out = (ctypes.c_uint8 * 64)()
-    seen, reply = [], [bytes(64)]
-
-    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
-    def fake_op_host(p_in, p_out, n, stream):
-        seen.append(ctypes.string_at(p_in, 64))
-        ctypes.memmove(p_out, reply[0], 64)
-        return 0
-    _fastboard.init(ctypes.cast(fake_op_host, ctypes.c_void_p).value, ctypes.addressof(buf_in), ctypes.addressof(buf_out))
-    rng = random.Random(11)
-
-    def random_sets(k):
-        out = []
-        for _ in range(k):
-            out.append(set(rng.sample(range(9), rng.randint(1, 5))))
-        return out
-
-    def random_out_record(old_q):
-        n = rng.randint(0, 9)
-        r = bytearray(64)
-        for i in range(9):
-            r[2 * i], r[2 * i + 1] = (rng.randrange(9), rng.randrange(9)) if i < n else (255, 255)
-        r[18] = n
-        for v in range(9):
-            r[19 + v] = rng.choice([255, 255] + list(range(9)))
-        # new components: some equal to old ones, some grown from old ones, some new
-        new = []
-        for s in old_q:
-            c = rng.random()
-            if c < 0.4:
-                new.append(set(s))
-            elif c < 0.7:
-                new.append(set(s) | set(rng.sample(range(9), 2)))
-        if rng.random() < 0.5:
-            new.append(set(rng.sample(range(9), 2)))
-        new = new[:4]
-        rng.shuffle(new)
-        r[28] = len(new)
-        for k, s in enumerate(new):
-            m = sum(1 << x for x in s)
-            r[30 + 2 * k], r[31 + 2 * k] = m & 255, m >> 8
-        r[49], r[50] = rng.choice([255, 4, 6, 8]), rng.choice([255, 5, 7])
-        return bytes(r)
-
-    def make_board():
-        b = Board(QEvalClassic())
-        n = rng.randint(0, 9)
-        b.moves = [(rng.randrange(9), rng.randrange(9), i) for i in range(n)]
-        b.board = [rng.choice([-1, -1] + list(range(9))) for _ in range(9)]
-        b.qstructs = random_sets(rng.randint(0, 4))
-        return b
-
-    def clone(b):
-        c = Board(b.qeval)
-        c.moves, c.board, c.qstructs = list(b.moves), list(b.board), [set(s) for s in b.qstructs]
-        return c
-
-    for case in range(400):
-        a = make_board()
-        b = clone(a)
-        op, lo, hi, bit, drop = rng.randrange(3), rng.randrange(9), rng.randrange(9), rng.randrange(2), bool(a.moves) and rng.random() < 0.3
-        reply[0] = random_out_record(a.qstructs)
-        want_in = _Staging.pack(a, op, lo, hi, bit, drop)
-        olds_a = (a.moves, a.board, a.qstructs, list(a.qstructs))
-        olds_b = (b.moves, b.board, b.qstructs, list(b.qstructs))
-        a._adopt(reply[0])                                            # Python
-        assert _fastboard.board_op(b, op, lo, hi, bit, drop, 0) == 0  # C
-        assert seen[-1][:41] == want_in, case
-        assert (a.moves, a.board, a.qstructs, a._win) == (b.moves, b.board, b.qstructs, b._win), case
-        assert all(type(m) is tuple and all(type(x) is int for x in m) for m in b.moves)
-        # aliasing: the three attribute objects are the ones the caller held; per component, an old set object survives
-        # in b exactly where the corresponding one survives in a
-        assert b.moves is olds_b[0] and b.board is olds_b[1] and b.qstructs is olds_b[2]
-        ida = [next((j for j, t in enumerate(olds_a[3]) if t is s), None) for s in a.qstructs]
-        idb = [next((j for j, t in enumerate(olds_b[3]) if t is s), None) for s in b.qstructs]
-        assert ida == idb, (case, ida, idb)
-    # attributes of unusual types are declined (-100), nothing is touched: the Python path then deals with them
-    odd = make_board()
-    odd.board = tuple(odd.board)
-    before = len(seen)
-    assert _fastboard.board_op(odd, 0, 0, 1, 0, False, 0) == -100 and len(seen) == before
-    odd = make_board()
-    odd.qstructs = [frozenset({0, 1}), [2, 3]]
-    assert _fastboard.board_op(odd, 0, 0, 1, 0, False, 0) == -100
-    odd = make_board()
-    odd.moves = [(0.0, 1, 0)]
-    assert _fastboard.board_op(odd, 0, 0, 1, 0, False, 0) == -100
-    # an error code of the library comes back as it is, attributes untouched
-
-    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
-    def failing(p_in, p_out, n, stream):
-        return 719
-    _fastboard.init(ctypes.cast(failing, ctypes.c_void_p).value, ctypes.addressof(buf_in), ctypes.addressof(buf_out))
-    keep = make_board()
-    snap = (list(keep.moves), list(keep.board), [set(s) for s in keep.qstructs])
-    assert _fastboard.board_op(keep, 0, 0, 1, 0, False, 0) == 719
-    assert (keep.moves, keep.board, keep.qstructs) == snap

@@ -82,8 +82,8 @@ def test_the_tail_of_the_default_line_carries_the_baseline_configs():
     sees BASELINE configs 2 / 3 / 5 and the beyond-cache fraction."""
     out, lines = bench("--cpu-budget", "2")
     line = lines[0]
-    tail = line[-600:]
-    for k in ("config2_us", "config3_us", "config3_frac", "config5_us", "beyond_cache_frac"):
+    tail = line[-800:]
+    for k in ("config2_us", "config3_us", "config3_frac", "config5_us", "beyond_cache_frac", "gym_default_us", "gym_default_eager_us"):
         assert '"%s"' % k in tail, (k, tail)
     d = json.loads(line)
     assert list(d)[-1] == "configs"                                   # after legs and cpu_baseline
@@ -95,6 +95,12 @@ def test_the_tail_of_the_default_line_carries_the_baseline_configs():
                                                          "beyond_cache_frac_of_achievable"))
     assert c["config2_us"] == legs["config2_4096_boards"]["us_per_step"] and c["config3_us"] == legs["config3_262144_boards"]["us_per_step"]
     assert c["config5_us"] == legs["config5_expand_rollout_65536_pairs"]["us_per_unit"]
+    # the default gym call: device-paced and by the region clock, beside the zero-copy form
+    g = legs["gym_default_1048576_boards"]
+    assert c["gym_default_us"] == g["device_paced_us_per_step"] and c["gym_default_eager_us"] == g["us_per_step"]
+    assert c["gym_us"] == legs["gym_1048576_boards"]["us_per_step"]
+    assert g["replay_matches_recording"] is True and g["output_sets_in_use"] <= 4 and g["mode"] == "gym-default"
+    assert g["device_paced_us_per_step"] < 13.0 + 1.5, g       # asked: <= 13 us on a typical box (the pool's boxes differ by 7 %)
     assert abs(c["config1_us"] - d["ms_per_step"] * 1e3) < 1e-9 and abs(c["config1_frac"] - r["frac"]) < 1e-12
 
 
