@@ -234,7 +234,8 @@ def cpu_baseline(actions_host, seed, budget_s):
 
 def python_interpreter_line(actions_host, seed, budget_s=2.0):
     """The like-for-like interpreter-speed line: oracle/py_env.py, a pure-Python
-    single-board restatement with the reference's own data structures, one core, ~2 s."""
+    single-board restatement with the reference's own data structures returning what Env.step returns (the
+    observation dict too, env.py:46,68-85), one core, ~2 s."""
     import oracle
     from oracle.py_env import PyEnv
     T = actions_host.shape[0]
@@ -246,7 +247,7 @@ def python_interpreter_line(actions_host, seed, budget_s=2.0):
         env = PyEnv()
         for t in range(min(T, 64)):
             a0, a1 = int(actions_host[t, b, 0]), int(actions_host[t, b, 1])
-            _, term = env.step(a0, a1, oracle.collapse_bit(seed, b, t))
+            _, _, term, _, _ = env.step_full(a0, a1, oracle.collapse_bit(seed, b, t))     # observation included (env.py:46)
             done += 1
             if term:
                 env.reset()          # auto-reset, like the workload

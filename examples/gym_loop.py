@@ -3,7 +3,7 @@
 for N boards at once: a policy that reads the observation tensors on the GPU and answers with an
 action per board, auto-reset on, episode statistics accumulated on the device.
 
-    python examples/gym_loop.py [--boards 262144] [--steps 200] [--graph]
+    python examples/gym_loop.py [--boards 262144] [--steps 200] [--graph | --fresh]
 
 --graph: one whole agent step (policy reading the observation, env.step, the statistics) is captured in a hipGraph
 and replayed: possible because the step index lives on the device (VecEnv.use_device_step_counter), so every
@@ -16,7 +16,9 @@ policy that depends on `obs["classical"]`.
 Aliasing: the loop consumes each observation at once, so it asks for the zero-copy form
 (`copy_obs=False`: the returned tensors are the environment's own buffers and the NEXT step overwrites
 them).  A caller that keeps observations — a replay buffer storing (obs, next_obs) — uses the default
-`env.step(action)`, which returns fresh tensors every call.
+`env.step(action)`, which returns fresh tensors every call, still from ONE kernel: `--fresh` runs the loop that way
+(the names are rebound every step, so the environment alternates between two sets of output tensors and allocates
+nothing per step).
 """
 import argparse
 import os
@@ -49,15 +51,23 @@ def main():
     ap.add_argument("--boards", type=int, default=262144)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--fresh", action="store_true", help="the default env.step(): fresh output tensors every call")
     args = ap.parse_args()
+    if args.graph and args.fresh:
+        ap.error("--graph replays ONE captured step: it needs the in-place form")
     env = VecEnv(args.boards, seed=1, auto_reset=True)
     obs, _ = env.reset(copy_obs=False)                          # the environment's own buffers: every step refreshes them
     episodes = torch.zeros((), dtype=torch.int64, device=env.device)
     lines = torch.zeros((), dtype=torch.int64, device=env.device)
 
+    state = {"obs": obs}
+
     def agent_step():
-        # obs are the environment's own buffers: the step overwrites them in place (copy_obs=False)
-        _, reward, terminated, truncated, info = env.step(policy(env, obs), copy_obs=False)
+        if args.fresh:                                         # the gym loop as written against the reference
+            state["obs"], reward, terminated, truncated, info = env.step(policy(env, state["obs"]))
+        else:
+            # obs are the environment's own buffers: the step overwrites them in place (copy_obs=False)
+            _, reward, terminated, truncated, info = env.step(policy(env, obs), copy_obs=False)
         episodes.add_(terminated.sum())
         lines.add_((reward != 0).sum())                        # env.py:49: -1.0 iff somebody holds a line
 

@@ -98,7 +98,7 @@ class PyEnv:
     def reset(self):                                      # env.py:55-57
         self.b = PyBoard()
 
-    def step(self, a, b, bit):                            # env.py:34-53
+    def step(self, a, b, bit):                            # env.py:34-53 without the observation
         try:
             self.b.make_move(a, b, bit)
         except Exception:
@@ -106,3 +106,24 @@ class PyEnv:
         p1, p2 = self.b.check_win()
         r = (-1 ** 0) * float(p1 > 0 or p2 > 0)           # env.py:49: -(1 ** cur_player) * float(win)
         return r, (p1 > 0 or p2 > 0) or len(self.b.moves) > 8
+
+    def observation(self):                                # env.py:68-85
+        q1, q2 = [], []
+        board = self.b.board
+        for i, m in enumerate(self.b.moves):
+            if i not in board:                            # a move is collapsed iff its round is on the board (:72-74)
+                (q2 if i % 2 else q1).append((m[0], m[1]))
+        return {"q_states_p1": q1, "q_states_p2": q2, "classical": board, "turn": len(self.b.moves) % 2}
+
+    def step_full(self, a, b, bit):
+        """What the reference's Env.step returns (env.py:34-53), observation included: the like-for-like interpreter
+        line beside the GPU numbers (bench.py cpu_baseline.python_interpreter_steps_per_s, tools/facade_latency.py)."""
+        cur_player = len(self.b.moves) % 2                # env.py:35
+        try:
+            self.b.make_move(a, b, bit)
+        except Exception:
+            pass
+        obs = self.observation()                          # env.py:46
+        p1, p2 = self.b.check_win()
+        r = (-1 ** cur_player) * float(p1 > 0 or p2 > 0)  # env.py:49, verbatim precedence
+        return obs, r, (p1 > 0 or p2 > 0) or len(self.b.moves) > 8, False, {}

@@ -63,15 +63,27 @@ def kfd_gpus(root=KFD_NODES):
     return gpus
 
 
+def _hip_level(environ):
+    """HIP_VISIBLE_DEVICES and CUDA_VISIBLE_DEVICES are ONE remapping level of the HIP runtime, not two: the CUDA_ name is
+    an alias that is read only when the HIP_ name is unset (launchers commonly export both with the same list — applying
+    both would map a permutation twice and pin a rank to another GPU's cores)."""
+    v = environ.get("HIP_VISIBLE_DEVICES")
+    if v is None or v.strip() == "":
+        v = environ.get("CUDA_VISIBLE_DEVICES")
+    return v
+
+
+def _levels(environ):
+    """the remapping levels in effect, inner (HIP runtime) -> outer (ROCr), as strings"""
+    return [v for v in (_hip_level(environ), environ.get("ROCR_VISIBLE_DEVICES")) if v is not None and v.strip() != ""]
+
+
 def visible_index(local_index, environ=None):
-    """the KFD-order index behind HIP device `local_index`, through ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES when they are plain
-    integer lists (a UUID list is not resolved: None)"""
+    """the KFD-order index behind HIP device `local_index`, through HIP_ (or, when that is unset, CUDA_) VISIBLE_DEVICES and
+    then ROCR_VISIBLE_DEVICES when they are plain integer lists (a UUID list is not resolved: None)"""
     environ = os.environ if environ is None else environ
     idx = local_index
-    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):       # inner -> outer
-        v = environ.get(var)
-        if v is None or v.strip() == "":
-            continue
+    for v in _levels(environ):                                                               # inner -> outer
         try:
             ids = [int(x) for x in v.split(",")]
         except ValueError:
@@ -87,10 +99,7 @@ def visible_count(n_kfd, environ=None):
     list is not plain integers)"""
     environ = os.environ if environ is None else environ
     n = n_kfd
-    for var in ("ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):       # outer -> inner
-        v = environ.get(var)
-        if v is None or v.strip() == "":
-            continue
+    for v in reversed(_levels(environ)):                                                     # outer -> inner
         try:
             ids = [int(x) for x in v.split(",")]
         except ValueError:

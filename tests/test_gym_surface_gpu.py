@@ -214,3 +214,28 @@ def test_default_step_with_a_device_step_counter_and_inside_a_graph():
             assert torch.equal(got[t][0][k], want[t][0][k]), (t, k)
         assert torch.equal(got[t][1].view(torch.int32), want[t][1].view(torch.int32)) and torch.equal(got[t][2], want[t][2])
     assert torch.equal(env.state, ref.state)
+
+
+def test_step_returns_copies_by_default_and_takes_non_contiguous_inputs(golden):
+    """VecEnv.step() hands out fresh tensors (a caller that keeps (obs, next_obs) pairs must not see
+    them alias); copy_obs=False is the zero-copy form.  Transposed / strided uint8 device tensors are accepted."""
+    from qtttgym_amd import VecEnv
+    acts, bits = golden["actions"], golden["bits"]
+    E = bits.shape[0]
+    env, raw = VecEnv(E), VecEnv(E)
+    a0 = torch.from_numpy(acts[:, 0].copy()).cuda()
+    a1 = torch.from_numpy(acts[:, 1].copy()).cuda()
+    obs0, r0, t0, _, _ = env.step(a0.t().contiguous().t(), torch.from_numpy(bits[:, 0].copy()).cuda())   # (2,N).t(): not contiguous
+    keep = {k: v.clone() for k, v in obs0.items()}
+    wide = torch.zeros((E, 2), dtype=torch.uint8, device="cuda")
+    wide[:, 0] = torch.from_numpy(bits[:, 1].copy()).cuda()
+    obs1, r1, t1, _, _ = env.step(a1, wide[:, 0])                                                          # strided bits
+    for k in obs0:
+        assert obs0[k].data_ptr() != obs1[k].data_ptr() and torch.equal(obs0[k], keep[k]), k
+    assert r0.data_ptr() != r1.data_ptr()
+    assert np.array_equal(_np(obs1["classical"]), golden["board"][:, 1])
+    assert np.array_equal(_np(obs0["classical"]), golden["board"][:, 0])
+    o_a, _, _, _, _ = raw.step(a0, torch.from_numpy(bits[:, 0].copy()).cuda(), copy_obs=False)
+    o_b, _, _, _, _ = raw.step(a1, torch.from_numpy(bits[:, 1].copy()).cuda(), copy_obs=False)
+    assert all(o_a[k].data_ptr() == o_b[k].data_ptr() for k in o_a)                                      # the env's own buffers
+    assert np.array_equal(_np(o_b["classical"]), golden["board"][:, 1])

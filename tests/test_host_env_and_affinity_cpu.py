@@ -1,12 +1,11 @@
-"""Round 5, CPU side: the package leaves the environment alone, the NUMA binding helper on a made-up sysfs tree, the
-per-rank bookkeeping collectives with EIGHT gloo ranks, the evaluator plug point's rule."""
+"""Host-side behaviour with no GPU: importing the package leaves os.environ alone (recommended_env() is the documented
+helper), and the NUMA binding helper (qtttgym_amd/affinity.py) on a made-up sysfs tree, incl. the *_VISIBLE_DEVICES
+remapping levels, and really binding in a child process."""
 import os
-import socket
 import subprocess
 import sys
 
 import pytest
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -72,6 +71,15 @@ def test_affinity_helper_on_a_made_up_topology(tmp_path, monkeypatch):
     assert affinity.visible_count(8, {}) == 8 and affinity.visible_count(8, {"HIP_VISIBLE_DEVICES": "3"}) == 1
     assert affinity.visible_count(8, {"ROCR_VISIBLE_DEVICES": "0,1,2,3", "HIP_VISIBLE_DEVICES": "1,0"}) == 2
     assert affinity.visible_count(8, {"HIP_VISIBLE_DEVICES": "GPU-1234"}) is None
+    # HIP_ and CUDA_VISIBLE_DEVICES are ONE level (the CUDA_ name is read only when the HIP_ name is unset);
+    # a launcher that exports both with the same permuted list must not see the permutation applied twice
+    both = {"HIP_VISIBLE_DEVICES": "2,3,0,1", "CUDA_VISIBLE_DEVICES": "2,3,0,1"}
+    assert [affinity.visible_index(k, both) for k in range(4)] == [2, 3, 0, 1] and affinity.visible_count(8, both) == 4
+    assert affinity.visible_index(0, {"CUDA_VISIBLE_DEVICES": "5,4"}) == 5                       # alone, the alias counts
+    assert affinity.visible_index(0, {"HIP_VISIBLE_DEVICES": "1", "CUDA_VISIBLE_DEVICES": "7"}) == 1   # HIP_ wins
+    upper = {"HIP_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": "4,5,6,7"}
+    assert affinity.visible_count(8, upper) == 4 and affinity.visible_index(3, upper) == 7
+    assert affinity.visible_index(1, dict(both, ROCR_VISIBLE_DEVICES="7,6,5,4")) == 4             # HIP 1 -> ROCr 3 -> KFD 4
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")                    # HIP device 0 is KFD GPU 1
     assert affinity.visible_index(0) == 1 and affinity.bind_to_gpu(0, kfd, pci, apply=False)["numa_node"] == 1
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")             # a UUID list is not resolved
@@ -94,50 +102,3 @@ def test_affinity_really_binds_in_a_child_process(tmp_path):
     import json
     a, now = json.loads(out.stdout)
     assert a["bound"] is True and now == half and a["cpus"] == len(half)
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _rank_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    from qtttgym_amd.dist import init_from_env, gather_rank_values, agree, shard_range
-    init_from_env(backend="gloo")
-    rows = gather_rank_values([1.0 + rank, 0.5 + rank, 10.0 * rank])
-    ok_all = agree(True)
-    ok_one_fails = agree(rank != 5)                      # rank 5 "failed to prepare": every rank must learn it
-    q.put((rank, rows, ok_all, ok_one_fails, shard_range(2097152, rank, world)))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.timeout(300)
-def test_per_rank_bookkeeping_with_eight_gloo_ranks():
-    """The N = 8 shape of bench.py's bookkeeping off the timed path: per-rank timings in rank order on
-    every rank, the all-or-none agreement in front of an optional collective, BASELINE config 4's shard offsets."""
-    world, port = 8, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in range(world))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    want = [[1.0 + r, 0.5 + r, 10.0 * r] for r in range(world)]
-    for rank, rows, ok_all, ok_one_fails, (lo, hi) in res:
-        assert rows == want and ok_all is True and ok_one_fails is False
-        assert (lo, hi) == (rank * 262144, (rank + 1) * 262144)
-    from qtttgym_amd.dist import gather_rank_values, agree
-    assert gather_rank_values([3, 4]) == [[3.0, 4.0]] and agree(True) is True and agree(False) is False   # no process group
-
-

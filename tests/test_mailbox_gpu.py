@@ -30,7 +30,7 @@ _STEP_AFTER_BOARD = r"""
 import sys, json, time
 sys.path.insert(0, %r)
 import torch
-from qtttgym_amd import Board, QEvalClassic, VecEnv
+from qtttgym_amd import Board, QEvalClassic, VecEnv, retire_mailbox
 n = 1 << 20
 env = VecEnv(n, seed=1, auto_reset=True)
 T = 64
@@ -40,34 +40,37 @@ for t in range(T):
 torch.cuda.synchronize()
 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
 MOVES = [(0, 1), (2, 3), (4, 5), (6, 7)]
-def loop(with_board, K=9, reps=150):
-    # K back-to-back 1 M-board steps right after one Board.make_move; HIP events around the FIRST step and around the
-    # K - 1 that follow
-    first, rest = [], []
-    b, k = Board(QEvalClassic()), 0
-    for r in range(reps):
-        if with_board:
-            if k == len(MOVES): b, k = Board(QEvalClassic()), 0
-            b.make_move(MOVES[k]); k += 1
-        e0.record()
-        env.step_raw(acts[(r * K) %% T])
-        e1.record()
-        for t in range(1, K):
-            env.step_raw(acts[(r * K + t) %% T])
-        e2.record()
-        torch.cuda.synchronize()
-        first.append(e0.elapsed_time(e1) * 1e3)
-        rest.append(e1.elapsed_time(e2) * 1e3 / (K - 1))
-    first.sort(); rest.sort()
-    return first[len(first) // 2], rest[len(rest) // 2]
-loop(True, reps=20); loop(False, reps=20)
-res = {"after_board_first_us": [], "after_board_rest_us": [], "alone_first_us": [], "alone_rest_us": []}
-for _ in range(5):                                    # alternating, one process, one box
-    f, r = loop(True); res["after_board_first_us"].append(f); res["after_board_rest_us"].append(r)
-    f, r = loop(False); res["alone_first_us"].append(f); res["alone_rest_us"].append(r)
+def region(with_board, K, state):
+    # K back-to-back 1 M-board steps right after one Board.make_move (or after nothing); HIP events around the FIRST
+    # step and around the K - 1 that follow
+    if with_board:
+        if state["k"] == len(MOVES): state["b"], state["k"] = Board(QEvalClassic()), 0
+        state["b"].make_move(MOVES[state["k"]]); state["k"] += 1
+    else:
+        retire_mailbox()                              # "alone" = really alone (a no-op unless a wave is still resident)
+    r = state["r"]; state["r"] += 1
+    e0.record()
+    env.step_raw(acts[(r * K) %% T])
+    e1.record()
+    for t in range(1, K):
+        env.step_raw(acts[(r * K + t) %% T])
+    e2.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3, e1.elapsed_time(e2) * 1e3 / (K - 1)
+state = {"b": Board(QEvalClassic()), "k": 0, "r": 0}
+for _ in range(40):
+    region(True, 9, state); region(False, 9, state)
+first = {True: [], False: []}
+rest = {True: [], False: []}
+for _ in range(400):                                  # alternating region by region: drift of the box cancels
+    for wb in (True, False):
+        f, r = region(wb, 9, state)
+        first[wb].append(f); rest[wb].append(r)
 med = lambda x: sorted(x)[len(x) // 2]
-res["delta_first"] = med(res["after_board_first_us"]) - med(res["alone_first_us"])
-res["delta_rest"] = med(res["after_board_rest_us"]) - med(res["alone_rest_us"])
+res = {"after_board_first_us": med(first[True]), "alone_first_us": med(first[False]),
+       "after_board_rest_us": med(rest[True]), "alone_rest_us": med(rest[False])}
+res["delta_first"] = res["after_board_first_us"] - res["alone_first_us"]
+res["delta_rest"] = res["after_board_rest_us"] - res["alone_rest_us"]
 print(json.dumps(res))
 print("ok")
 """
@@ -86,7 +89,7 @@ def test_a_chip_filling_step_right_after_a_board_call_does_not_pay_for_the_wave(
     print(json.dumps({"mailbox_on": on, "mailbox_off": off, "mailbox_on_never_retired": keep}))
     d = (on["delta_first"], on["delta_rest"], off["delta_first"], off["delta_rest"], keep["delta_first"], keep["delta_rest"])
     # launches 2..9 after a Board call: what they cost alone, and what they cost with no mailbox in the process
-    assert abs(on["delta_rest"]) < 0.2 and abs(on["delta_rest"] - off["delta_rest"]) < 0.2, d
+    assert abs(on["delta_rest"]) < 0.2 and abs(on["delta_rest"] - off["delta_rest"]) < 0.25, d
     # the first launch: never worse than the partial round a resident wave costs (+1.4 us) + the box's scatter
     assert on["delta_first"] < 1.9, d
     # and the rule is what makes the difference: never retired, every launch inside the idle window pays

@@ -112,3 +112,14 @@ def test_pure_python_restatement_matches_golden(golden):
             assert len(env.b.moves) == int(golden["n_moves"][e, t])
             assert np.float64(r).view(np.uint64) == golden["reward"][e, t].view(np.uint64)
             assert term == bool(golden["terminated"][e, t])
+    # ... and the form that returns what the reference's Env.step returns, observation included (env.py:46,68-85)
+    for e in range(1, acts.shape[0], 7):
+        env = PyEnv()
+        for t in range(acts.shape[1]):
+            obs, r, term, trunc, info = env.step_full(int(acts[e, t, 0]), int(acts[e, t, 1]), int(bits[e, t]))
+            assert np.float64(r).view(np.uint64) == golden["reward"][e, t].view(np.uint64)
+            assert term == bool(golden["terminated"][e, t]) and trunc is False and info == {}
+            assert obs["classical"] == golden["board"][e, t].tolist() and obs["turn"] == int(golden["turn"][e, t])
+            for key, g, ln in (("q_states_p1", "q_p1", "q_p1_len"), ("q_states_p2", "q_p2", "q_p2_len")):
+                k = int(golden[ln][e, t])
+                assert [list(p) for p in obs[key]] == golden[g][e, t, :k].tolist(), (e, t, key)

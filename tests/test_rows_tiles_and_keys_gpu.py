@@ -1,18 +1,13 @@
-"""Round 4 on the GPU (through the C ABI):
-  * the playout loop against the fixture recorded from the reference's own MCTS._rollout / _simulate / _reward
-    (tests/golden/playout_traces.npz, make_golden_playout.py): qttt_rollout, qttt_rollout_many, qttt_expand_rollout;
-  * the packed state is a canonical form of (board, moves): qttt_import(qttt_export(s)) == s bit for bit at every
-    depth, and the native position key is equal exactly where CPython's hash of (board, moves) is;
-  * qttt_expand_rollout == qttt_expand followed by qttt_rollout_many on each child;
-  * the policy-in-the-step kernel (nth9 table + trusted step) == policy kernel + step kernel in every launch shape;
-  * the Board façade mutates its attributes in place, as the reference does.
-"""
+"""The kernels either side of the step (SURVEY.md §8f rows and the Board-attribute forms) at ragged sizes, on misaligned
+views and with re-used outputs: export / import tiles, node_info and expand pairs, rollout / rollout_many /
+expand_rollout against the reference's recorded playouts and the oracle, encode; import(export(s)) == s; the native
+position key against CPython's hash on the reference's own children, on a million boards and on every position reachable
+in four plies; every transition from every position to depth three against the oracle."""
 import os
 
 import numpy as np
 import pytest
 import torch
-
 import oracle
 
 pytestmark = pytest.mark.gpu
@@ -21,6 +16,295 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _np(t):
     return t.cpu().numpy()
+
+
+def _assert_same_as_oracle(env, ob, tag="", sel=slice(None)):
+    ex = {k: _np(v) for k, v in env.export_boards().items()}
+    assert np.array_equal(ex["board"][sel], ob.board[sel]), tag
+    assert np.array_equal(ex["n_moves"][sel], ob.n_moves[sel]), tag
+    assert np.array_equal(ex["moves"][sel], ob.moves[sel]), tag
+    assert np.array_equal(ex["n_q"][sel], ob.n_q[sel]), tag
+    assert np.array_equal(ex["qmask"].view(np.uint16)[sel], ob.qmask[sel]), tag
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000, 65536 + 7])
+def test_export_tiles_every_subset_and_misaligned_views(n):
+    """qttt_export writes through LDS tiles; any subset of its outputs may be asked for, and outputs that are
+    views offset by one board (every alignment phase of the tile copy) give the same rows."""
+    from qtttgym_amd import VecEnv
+    seed = 17 + n
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    for t in range(8):
+        a = ob.sample_actions(seed, t, 0, False)
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t, 0, False)
+    want = {"moves": ob.moves, "n_moves": ob.n_moves, "board": ob.board, "qmask": ob.qmask.view(np.int16), "n_q": ob.n_q}
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    spec = dict((k, (dt, shp)) for k, dt, shp in VecEnv._EXPORT_SPEC)
+    order = ["moves", "n_moves", "board", "qmask", "n_q"]
+    for mask in range(1, 32):
+        bufs = {k: torch.full((n + 1,) + spec[k][1], 77, dtype=spec[k][0], device="cuda") for k in order}
+        sel = [k for j, k in enumerate(order) if mask >> j & 1]
+        # odd masks write whole tensors, even ones views that start one board in
+        first = 0 if mask & 1 else 1
+        ptrs = [bufs[k][first:].data_ptr() if k in sel else None for k in order]
+        assert L.qttt_export(env.state.data_ptr(), *ptrs, n, s) == 0
+        for k in order:
+            got = _np(bufs[k])
+            if k in sel:
+                assert np.array_equal(got[first:first + n], want[k]), (mask, k)
+                assert (got[:first] == 77).all() and (got[first + n:] == 77).all(), (mask, k)
+            else:
+                assert (got == 77).all(), (mask, k)
+    assert np.array_equal(_np(env.turn()), ob.n_moves)
+    buf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert env.turn(out=buf) is buf and np.array_equal(_np(buf), ob.n_moves)
+    ex = env.export_boards()
+    for v in ex.values():
+        v.zero_()
+    assert env.export_boards(out=ex) is ex
+    for k in order:
+        assert np.array_equal(_np(ex[k]), want[k]), k
+    with pytest.raises(ValueError):
+        env.export_boards(out={**ex, "board": ex["board"][:, :8]})
+
+
+def test_export_at_the_end_of_the_game_nine_moves_and_autofill():
+    """Boards played to the end: nine real moves (round 8's x kept in the `last x` field), implicit
+    autofill moves, finished boards — every depth in one batch."""
+    from qtttgym_amd import VecEnv
+    n, seed = 20000, 8
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    for t in range(11):
+        a = ob.sample_actions(seed, t, 0, False)
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t, 0, False)
+        _assert_same_as_oracle(env, ob, t)
+    nm = ob.n_moves
+    assert (nm == 9).sum() > n // 2
+    auto = (ob.moves[np.arange(n), np.minimum(nm, 9) - 1, 0] == ob.moves[np.arange(n), np.minimum(nm, 9) - 1, 1])
+    assert auto.sum() > 100 and (~auto).sum() > 100          # both kinds of ninth move are present
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 4097, 100001])
+def test_node_info_pairs_and_expand_pairs_at_ragged_sizes(n):
+    """Two boards per lane in node_info (the last board of an odd batch alone), outputs as offset views
+    (scalar-store path), and the paired children of expand, against the oracle."""
+    from qtttgym_amd import VecEnv
+    seed = 23
+    env = VecEnv(n, seed=seed)
+    ob = oracle.OracleBoards(n)
+    rng = np.random.default_rng(n)
+    depth = rng.integers(0, 10, size=n)
+    for t in range(9):                                    # boards frozen at random depths 0..9
+        a = ob.sample_actions(seed, t, 0, False)
+        a[depth <= t] = 0                                  # (0,0): a noop
+        env.step_raw(torch.from_numpy(a).cuda())
+        ob.step(a, None, seed, t, 0, False)
+    w, tm, lg, ky = oracle.node_info(ob) if n <= 5000 else (None,) * 4
+    info = env.node_info()
+    if w is not None:
+        assert np.array_equal(_np(info["winner"]), w) and np.array_equal(_np(info["terminal"]).astype(np.uint8), tm)
+        assert np.array_equal(_np(info["legal"]).view(np.uint64), lg) and np.array_equal(_np(info["key"]), ky)
+    # offset views: one element in (misaligned for the vector stores) -> same values
+    big = {"winner": torch.zeros(n + 1, dtype=torch.int8, device="cuda"), "terminal": torch.zeros(n + 1, dtype=torch.bool, device="cuda"),
+           "legal": torch.zeros(n + 1, dtype=torch.int64, device="cuda"), "key": torch.zeros(n + 1, dtype=torch.int64, device="cuda")}
+    view = {k: v[1:] for k, v in big.items()}
+    env.node_info(out=view)
+    for k in big:
+        assert torch.equal(view[k], info[k]), k
+        assert int(big[k][0]) == 0, k
+    if n <= 5000:
+        act = rng.integers(0, 40, size=n).astype(np.uint8)      # 36..39: not an action
+        nch, kids, ow, ot, ol, ok = oracle.expand(ob, act)
+        out = env.expand(torch.from_numpy(act).cuda())
+        assert np.array_equal(_np(out["n_children"]), nch)
+        assert np.array_equal(_np(out["winner"]), ow) and np.array_equal(_np(out["terminal"]).astype(np.uint8), ot)
+        assert np.array_equal(_np(out["legal"]).view(np.uint64), ol) and np.array_equal(_np(out["key"]), ok)
+        for c in range(2):                                   # child c is meaningful where c < n_children (include/qttt.h)
+            _assert_same_as_oracle(out["child%d" % c], kids[c], (n, c), sel=nch > c)
+        # out= : the same buffers, overwritten
+        keep = {k: (v.state.data_ptr() if k.startswith("child") else v.data_ptr()) for k, v in out.items()}
+        for k, v in out.items():
+            (v.state if k.startswith("child") else v).zero_()
+        again = env.expand(torch.from_numpy(act).cuda(), out=out)
+        assert again is out
+        assert keep == {k: (v.state.data_ptr() if k.startswith("child") else v.data_ptr()) for k, v in out.items()}
+        assert np.array_equal(_np(out["key"]), ok) and np.array_equal(_np(out["n_children"]), nch)
+        for c in range(2):
+            _assert_same_as_oracle(out["child%d" % c], kids[c], (n, c, "out="), sel=nch > c)
+
+
+def test_expand_wants_aligned_rows():
+    from qtttgym_amd import VecEnv
+    n = 64
+    env = VecEnv(n)
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    c0, c1 = torch.empty_like(env.state), torch.empty_like(env.state)
+    nch = torch.empty(n, dtype=torch.uint8, device="cuda")
+    w = torch.empty(2 * n + 8, dtype=torch.int8, device="cuda")
+    tm = torch.empty(2 * n + 8, dtype=torch.uint8, device="cuda")
+    lg = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
+    ky = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
+    sk = torch.empty(2 * n + 2, dtype=torch.int64, device="cuda")
+    ok = lambda wp, tp, lp, kp, sp=sk.data_ptr(): L.qttt_expand(env.state.data_ptr(), a.data_ptr(), c0.data_ptr(), c1.data_ptr(),
+                                                                nch.data_ptr(), wp, tp, lp, kp, sp, n, s)
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr()) == 0
+    assert ok(w.data_ptr() + 1, tm.data_ptr(), lg.data_ptr(), ky.data_ptr()) == -3
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr() + 8, ky.data_ptr()) == -3
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr() + 8) == -3
+    assert ok(w.data_ptr(), tm.data_ptr(), lg.data_ptr(), ky.data_ptr(), sk.data_ptr() + 8) == -3
+    assert ok(None, None, None, None, None) == 0                      # every per-child row is nullable
+
+
+def test_rollout_and_encode_out_reuse():
+    from qtttgym_amd import VecEnv
+    n = 5000
+    env = VecEnv(n, seed=3)
+    for _ in range(3):
+        env.step_raw(env.sample_actions())
+    res, pl, fin = env.rollout(return_final=True)
+    planes = lambda st: st.view(torch.int64).view(2, -1)[:, :n]      # P | Q planes without the padding to 64 boards
+    ref = (res.clone(), pl.clone(), planes(fin.state).clone())
+    res.zero_(); pl.zero_(); fin.state.zero_()
+    out = env.rollout(return_final=True, out=(res, pl, fin))
+    assert out[0] is res and out[2] is fin
+    assert torch.equal(res, ref[0]) and torch.equal(pl, ref[1]) and torch.equal(planes(fin.state), ref[2])
+    r2 = env.rollout(out=(res, pl))
+    assert r2[0] is res and torch.equal(res, ref[0])
+    vec, mask = env.encode()
+    v0, m0 = vec.clone(), mask.clone()
+    vec.zero_(); mask.zero_()
+    v1, m1 = env.encode(out=(vec, mask))
+    assert v1 is vec and torch.equal(vec, v0) and torch.equal(mask, m0)
+    v2 = env.encode(with_mask=False, out=vec)
+    assert v2 is vec and torch.equal(vec, v0)
+    with pytest.raises(ValueError):
+        env.encode(out=(vec[:-1], mask))
+    with pytest.raises(ValueError):
+        env.rollout(out=(res[:-1], pl))
+
+
+def test_take_lines_boards_up_without_unpacking_them():
+    from qtttgym_amd import VecEnv
+    n = 1000
+    env = VecEnv(n, seed=8)
+    for _ in range(5):
+        env.step_raw(env.sample_actions())
+    idx = torch.tensor([3, 3, 999, 0, 3, 500], device="cuda")
+    sub = env.take(idx)
+    ex, sx = env.export_boards(), sub.export_boards()
+    for k in ex:
+        assert torch.equal(sx[k], ex[k][idx]), k
+    assert sub.num_envs == 6 and sub.seed == env.seed
+    rep = env.take(torch.arange(n, device="cuda").repeat_interleave(36))
+    assert rep.num_envs == 36 * n
+    out = rep.expand(torch.arange(36, dtype=torch.uint8, device="cuda").repeat(n))
+    legal = env.node_info()["legal"]
+    bits = ((legal[:, None] >> torch.arange(36, device="cuda")[None, :]) & 1).bool().reshape(-1)
+    assert torch.equal(out["n_children"] > 0, bits)                      # an action has children iff node_info calls it legal
+    assert env.take(torch.empty(0, dtype=torch.int64, device="cuda")).num_envs == 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 100003])
+def test_import_tiles_round_trip_misaligned_views_and_garbage(n):
+    """qttt_import (LDS tiles, nibble-parallel unpack, round-order insertion): export -> import -> export is the
+    identity at every depth incl. finished games, from whole tensors and from views offset by one board (every
+    alignment phase); the imported boards then step exactly like the originals; arbitrary bytes neither fault nor hang."""
+    from qtttgym_amd import VecEnv
+    seed = 5 + n
+    env = VecEnv(n, seed=seed)
+    rng = np.random.default_rng(n)
+    depth = torch.from_numpy(rng.integers(0, 11, n).astype(np.uint8)).cuda()
+    a = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(10):
+        env.sample_actions(out=a)
+        a[depth <= t] = 0
+        env.step_raw(a)
+    ex = env.export_boards()
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    order = ("moves", "n_moves", "board", "qmask", "n_q")
+    for first in (0, 1):
+        bufs = {}
+        for k in order:
+            big = torch.zeros((n + 1,) + tuple(ex[k].shape[1:]), dtype=ex[k].dtype, device="cuda")
+            big[first:first + n] = ex[k]
+            bufs[k] = big[first:first + n]
+        other = VecEnv(n, seed=seed)
+        assert L.qttt_import(other.state.data_ptr(), *[bufs[k].data_ptr() for k in order], n, s) == 0
+        back = other.export_boards()
+        for k in order:
+            assert torch.equal(back[k], ex[k]), (first, k)
+        assert torch.equal(other.check_win()[0], env.check_win()[0])
+        ia, ib = other.node_info(), env.node_info()
+        for k in ia:
+            assert torch.equal(ia[k], ib[k]), (first, k)
+        # the imported boards continue like the originals (same seed / step index / ids), attribute for attribute
+        cont = VecEnv.from_state(env.state.clone(), n, seed=seed)
+        cont.step_idx = other.step_idx = 50
+        for _ in range(4):
+            act = cont.sample_actions()
+            assert torch.equal(other.sample_actions(), act)
+            r1, t1 = cont.step_raw(act)
+            r2, t2 = other.step_raw(act)
+            assert torch.equal(r1.view(torch.int32), r2.view(torch.int32)) and torch.equal(t1, t2)
+        e1, e2 = cont.export_boards(), other.export_boards()
+        for k in order:
+            assert torch.equal(e1[k], e2[k]), (first, k, "after steps")
+    junk = VecEnv(n)
+    g = lambda shape, dt: torch.from_numpy(rng.integers(0, 256, size=shape, dtype=np.uint8)).cuda().view(dt)
+    junk.import_boards(g((n, 9, 2), torch.uint8), g((n,), torch.uint8), g((n, 9), torch.int8),
+                       g((n, 4, 2), torch.uint8).view(torch.int16).reshape(n, 4), g((n,), torch.uint8))
+    for _ in range(3):
+        junk.step_raw(junk.sample_actions())
+    jx = junk.export_boards()
+    torch.cuda.synchronize()                                             # garbage in, garbage out — but no fault and no hang
+    assert jx["n_moves"].shape == (n,) and int(jx["n_moves"].max()) <= 15
+
+
+def test_large_batch_shapes_of_export_and_node_info_on_ragged_offset_views():
+    """Above 384 K boards export runs two boards per lane and node_info / expand 1024-thread workgroups: an odd batch
+    size, outputs as views offset by one board (every alignment phase, the scalar-store paths), against the
+    whole-tensor results of the same kernels (which the oracle / the torch restatements pin elsewhere)."""
+    from qtttgym_amd import VecEnv
+    n = 400001
+    env = VecEnv(n, seed=21)
+    depth = (torch.arange(n, device="cuda") * 2654435761 % 11).to(torch.uint8)
+    a = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+    for t in range(10):
+        env.sample_actions(out=a)
+        a[depth <= t] = 0
+        env.step_raw(a)
+    ex = env.export_boards()
+    small = VecEnv.from_state(env.take(torch.arange(1000, device="cuda")).state, 1000)     # the same boards through the small-batch shape
+    sx = small.export_boards()
+    for k in ex:
+        assert torch.equal(ex[k][:1000], sx[k]), k
+    L, s = env._lib, torch.cuda.current_stream().cuda_stream
+    spec = dict((k, (dt, shp)) for k, dt, shp in VecEnv._EXPORT_SPEC)
+    order = ["moves", "n_moves", "board", "qmask", "n_q"]
+    bufs = {k: torch.full((n + 1,) + spec[k][1], 77, dtype=spec[k][0], device="cuda") for k in order}
+    assert L.qttt_export(env.state.data_ptr(), *[bufs[k][1:].data_ptr() for k in order], n, s) == 0
+    for k in order:
+        assert torch.equal(bufs[k][1:], ex[k]), k
+        assert bool((bufs[k][0] == 77).all()), k
+    info = env.node_info()
+    big = {"winner": torch.zeros(n + 1, dtype=torch.int8, device="cuda"), "terminal": torch.zeros(n + 1, dtype=torch.bool, device="cuda"),
+           "legal": torch.zeros(n + 1, dtype=torch.int64, device="cuda"), "key": torch.zeros(n + 1, dtype=torch.int64, device="cuda")}
+    env.node_info(out={k: v[1:] for k, v in big.items()})
+    si = small.node_info()
+    for k in big:
+        assert torch.equal(big[k][1:], info[k]) and int(big[k][0]) == 0, k
+        assert torch.equal(info[k][:1000], si[k]), k
+    act = torch.randint(0, 36, (n,), dtype=torch.uint8, device="cuda")
+    out, so = env.expand(act), small.expand(act[:1000].contiguous())
+    for k in ("n_children", "winner", "terminal", "legal", "key"):
+        assert torch.equal(out[k][:1000], so[k]), k
+    planes = lambda st, m: st.view(torch.int64).view(2, -1)[:, :m]
+    assert torch.equal(planes(out["child0"].state, n)[:, :1000], planes(so["child0"].state, 1000))
 
 
 def _load(name):
@@ -266,91 +550,6 @@ def test_native_key_equal_iff_python_key_equal_on_a_million_boards():
     assert torch.equal(other.state_keys(), nat)
 
 
-# ---------------------------------------------------------------------------------------- policy in the step kernel
-@pytest.mark.parametrize("n", [4096, 500 * 1024, 600 * 1024 + 3, 1 << 20, (1 << 21) + 64])
-@pytest.mark.parametrize("auto_reset", [True, False])
-def test_step_random_equals_policy_kernel_plus_step_in_every_shape(n, auto_reset):
-    """qttt_step_random (policy through the full n-th-empty-square table, trusted step under auto-reset) against
-    qttt_sample_actions + qttt_step, in each region of the launch-shape table."""
-    from qtttgym_amd import VecEnv
-    a_env = VecEnv(n, seed=77, auto_reset=auto_reset, board_offset=(1 << 32) - n // 2)   # ids cross 2^32
-    b_env = VecEnv(n, seed=77, auto_reset=auto_reset, board_offset=(1 << 32) - n // 2)
-    played = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
-    for t in range(12):
-        act = b_env.sample_actions()
-        rb, tb = b_env.step_raw(act)
-        ra, ta = a_env.step_random(actions_out=played)
-        assert torch.equal(played, act), t
-        assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(ta, tb), t
-    assert torch.equal(a_env.state, b_env.state)
-
-
-# ---------------------------------------------------------------------------------------- façade identity
-def test_board_attributes_are_mutated_in_place():
-    """board.py:19,25 append to .moves, :53-54 write into .board, :56-69 pop / assign / append on .qstructs and
-    grow a set with .add: a caller holding the list (or set) objects sees every move."""
-    from qtttgym_amd import Board, QEvalClassic
-
-    class Fixed(QEvalClassic):
-        def choose(self, lo, hi):
-            return hi
-
-    b = Board(Fixed())
-    mv, bd, qs = b.moves, b.board, b.qstructs
-    b.make_move((0, 1))
-    assert b.moves is mv and mv == [(0, 1, 0)] and b.qstructs is qs and qs == [{0, 1}] and b.board is bd
-    s0 = qs[0]
-    b.make_move((2, 1))
-    assert mv == [(0, 1, 0), (1, 2, 1)] and qs[0] is s0 and s0 == {0, 1, 2}          # board.py:68-69: grown in place
-    b.make_move((3, 4))
-    s1 = qs[1]
-    assert qs[0] is s0 and s1 == {3, 4}
-    b.make_move((5, 6))
-    s2 = qs[2]
-    b.make_move((2, 3))                                                              # board.py:58-61: union, a new set
-    assert b.qstructs is qs and qs == [{0, 1, 2, 3, 4}, {5, 6}] and qs[1] is s2 and qs[0] is not s0
-    b.make_move((0, 4))                                                              # closes a cycle: the component goes
-    assert b.qstructs is qs and qs == [{5, 6}] and qs[0] is s2
-    assert b.board is bd and bd == [0, 1, 4, 2, 5, -1, -1, -1, -1] and b.moves is mv and len(mv) == 6
-    with pytest.raises(Exception):
-        b.make_move((0, 5))
-    assert len(mv) == 6
-    # update_qstructs on its own (the caller appended the move, board.py:19-20) and make_moves keep identity too
-    b.moves.append((7, 8, len(b.moves)))
-    b.update_qstructs((7, 8))
-    assert b.moves is mv and len(mv) == 7 and qs == [{5, 6}, {7, 8}] and qs[0] is s2
-    c = Board(Fixed())
-    cm, cq = c.moves, c.qstructs
-    assert Board.make_moves([c], [(4, 8)]) == [None] and c.moves is cm and cm == [(4, 8, 0)] and c.qstructs is cq
-
-
-def test_board_op_host_polls_the_stamp_and_equals_board_op_sync():
-    """qttt_board_op_host (records in pinned host memory, completion by polling byte 63 of the out records) gives the
-    records qttt_board_op_sync gives, for one record, a node's 36 actions, and a batch beyond the polling limit."""
-    from qtttgym_amd import Board, QEvalClassic, _native
-    from qtttgym_amd.board import _Staging
-    L = _native.lib()
-    parent = Board(QEvalClassic())
-    for mv in ((0, 1), (1, 2), (3, 4), (2, 3), (5, 6), (0, 4)):         # the last one closes a cycle: squares 0..4 go classical
-        parent.make_move(mv)
-    pairs = [(i, j) for i in range(9) for j in range(i + 1, 9)]
-    s = torch.cuda.current_stream().cuda_stream
-    for n in (1, 36, 300):
-        recs = [_Staging.pack(parent, _native.OP_MAKE_MOVE, *pairs[k % 36], k & 1) for k in range(n)]
-        t_in = torch.zeros(64 * n, dtype=torch.uint8).pin_memory()
-        t_in.numpy()[:] = np.frombuffer(b"".join(r + bytes(23) for r in recs), dtype=np.uint8)
-        a = torch.full((64 * n,), 7, dtype=torch.uint8).pin_memory()
-        b = torch.full((64 * n,), 9, dtype=torch.uint8).pin_memory()
-        assert L.qttt_board_op_sync(t_in.data_ptr(), a.data_ptr(), n, s) == 0
-        assert L.qttt_board_op_host(t_in.data_ptr(), b.data_ptr(), n, s) == 0
-        ra, rb = a.numpy().reshape(n, 64), b.numpy().reshape(n, 64)
-        assert np.array_equal(ra[:, :42], rb[:, :42]) and np.array_equal(ra[:, 44:51], rb[:, 44:51])   # (bytes 42, 43 are padding)
-        assert (rb[:, 63] == (1 if n <= 256 else 9)).all()          # stamped when polled; untouched on the fallback path
-        if n > 1:                                                       # both kinds of answers are in the batch
-            assert (ra[:, 41] == 1).sum() > 0 and (ra[:, 41] == 0).sum() > 0
-    assert L.qttt_board_op_host(None, None, 1, s) == -1 and L.qttt_board_op_host(None, None, 0, s) == 0
-
-
 # ---------------------------------------------------------------------------------------- exhaustive: every position to depth 4
 def _cat_states(parts, seed=0):
     """One VecEnv over the boards of several (VecEnv, index tensor) selections (plane indexing, nothing unpacked)."""
@@ -450,14 +649,29 @@ def test_every_position_reachable_in_four_plies_has_its_own_key_and_survives_exp
     assert total > 1_500_000 and torch.unique(torch.cat(all_nat)).numel() == total      # no collision across depths either
 
 
-def test_root_ucb_search_on_expand_rollout_beats_random():
-    """The operator composes into a search loop with torch ops only (select -> one launch -> update): a root-level PUCT
-    bandit (mcts.py:281-285) over qttt_expand_rollout wins clearly more often as P1 than a random P1 does (52.8 % + its
-    share of the double-line games); measured 93.5 % (2 048 games, 72 iterations x 4 playouts per child)."""
-    import subprocess
-    import sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ucb_selfplay.py"), "--games", "512", "--iters", "48",
-                          "--sims", "4"], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    pct = float(out.stdout.split("(")[2].split("%")[0])
-    assert pct > 86.0, out.stdout
+def test_expand_out_dicts_with_missing_entries_raise_value_errors():
+    """a dict of expand() handed to expand_rollout() (no value_sum), python_key=True with a dict made without
+    the CPython key, a dict without a child: ValueError like every other bad `out`, never a bare KeyError."""
+    import torch
+    from qtttgym_amd import VecEnv
+    env = VecEnv(256, seed=5)
+    for _ in range(3):
+        env.step_raw(env.sample_actions())
+    act = torch.randint(0, 36, (256,), dtype=torch.uint8, device=env.device)
+    plain = env.expand(act, python_key=False)
+    assert "key" not in plain
+    with pytest.raises(ValueError, match="value_sum"):
+        env.expand_rollout(act, 2, out=plain)
+    with pytest.raises(ValueError, match="'key'"):
+        env.expand(act, out=plain, python_key=True)
+    again = env.expand(act, out=plain)                      # python_key=None: the dict's own choice
+    assert again is plain and "key" not in again
+    xr = env.expand_rollout(act, 2)
+    with pytest.raises(ValueError, match="result"):
+        env.expand_rollout(act, 2, out=xr, with_result=True)
+    broken = dict(plain)
+    del broken["child1"]
+    with pytest.raises(ValueError, match="child1"):
+        env.expand(act, out=broken)
+    fresh = env.expand(act)                                 # a fresh dict carries the CPython key by default
+    assert "key" in fresh and torch.equal(fresh["state_key"], plain["state_key"])

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Wall-clock cost of the single-board façades at N = 1, printed beside the
-reference's own ~12 us per Env.step (measured on one host core).  One JSON line."""
+"""Wall-clock cost of the single-board façades at N = 1, and beside it — same process, same host core,
+same random-play loop — the INTERPRETER running the reference's algorithm: oracle/py_env.py's PyEnv.step_full, the pure-
+Python restatement with the reference's own data structures that returns what Env.step returns (a tool may import the
+oracle; the product never does).  A GPU round trip per step cannot beat the interpreter on one board and need not: the
+façades exist so that reference-shaped callers run unchanged.  (SURVEY.md §8a's "~12 us per Env.step" was the survey
+container's Xeon @ 2.1 GHz; it is not comparable with numbers taken on the GPU box's host.)  One JSON line."""
 import json
 import os
 import random
@@ -38,9 +42,47 @@ def episodes(n_steps):
     return (time.perf_counter() - t0) / done_steps, in_step * 1e-9 / done_steps
 
 
+def interpreter_episodes(n_steps):
+    """the same loop through the pure-Python restatement of the reference (oracle/py_env.py): (s per step of the loop,
+    s per step call alone)"""
+    from oracle.py_env import PyEnv
+    rng = random.Random(3)
+    env = PyEnv()
+    done_steps, in_step = 0, 0
+    clock = time.perf_counter_ns
+    t0 = time.perf_counter()
+    while done_steps < n_steps:
+        empty = [i for i, v in enumerate(env.b.board) if v == -1]
+        if len(empty) < 2:
+            env.reset()
+            continue
+        a = rng.sample(empty, 2)
+        bit = rng.getrandbits(1)
+        c0 = clock()
+        _, _, term, _, _ = env.step_full(a[0], a[1], bit)
+        in_step += clock() - c0
+        done_steps += 1
+        if term:
+            env.reset()
+    return (time.perf_counter() - t0) / done_steps, in_step * 1e-9 / done_steps
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def main():
     episodes(200)                                            # warm: library load, pinned buffers, kernels
     t_env_loop, t_env = episodes(3000)
+    interpreter_episodes(500)
+    t_py_loop, t_py = interpreter_episodes(20000)
     b = Board(QEvalClassic())
     b.make_move((0, 1))
     n = 3000
@@ -93,11 +135,14 @@ def main():
     print(json.dumps({"row": "facade_latency_N1", "Env.step_us": t_env * 1e6, "Env.step_loop_us": t_env_loop * 1e6,
                       "Board.make_move_us": t_mm * 1e6, "Board.make_move_midgame_us": t_mid * 1e6,
                       "fastboard": board_mod._stage().fast is not None,
-                      "board_mailbox_us": os.environ.get("QTTT_BOARD_MAILBOX_US", "100 (default)"),
+                      "board_mailbox_us": os.environ.get("QTTT_BOARD_MAILBOX_US", "20 (default)"),
+                      "interpreter_Env.step_us": t_py * 1e6, "interpreter_Env.step_loop_us": t_py_loop * 1e6,
+                      "interpreter_steps_per_s": 1.0 / t_py, "facade_over_interpreter": t_env / t_py,
+                      "host_cpu": cpu_model(),
                       "expand_36_children_loop_of_make_move_us_per_child": t_loop * 1e6,
                       "expand_36_children_one_make_moves_call_us_per_child": t_batch * 1e6,
-                      "Board.check_win_us": t_cw * 1e6, "reference_Env.step_us": 12.0,
-                      "note": "Env.step_us = the env.step(action) call alone (perf_counter_ns around it); Env.step_loop_us = the whole random-play loop per step (also the random legal move and an Env.reset per episode: the figure of rounds 3 - 4). One step = one qttt_board_op_host call: a request to the resident mailbox wave (or, QTTT_BOARD_MAILBOX_US=0, a launch + polling the out record's stamp); check_win comes back in the same record"}))
+                      "Board.check_win_us": t_cw * 1e6,
+                      "note": "interpreter_Env.step_us = oracle/py_env.py PyEnv.step_full (the reference's algorithm and data structures, observation included) timed the same way in the same process: the like-for-like host number; the facade is a device round trip per call and is SLOWER than it. Env.step_us = the env.step(action) call alone (perf_counter_ns around it); Env.step_loop_us = the whole random-play loop per step (also the random legal move and an Env.reset per episode: the figure of rounds 3 - 4). One step = one qttt_board_op_host call: a request to the resident mailbox wave (or, QTTT_BOARD_MAILBOX_US=0, a launch + polling the out record's stamp); check_win comes back in the same record"}))
 
 
 if __name__ == "__main__":
