@@ -180,6 +180,19 @@ def cpu_model():
     return None
 
 
+def cgroup_cpu_max():
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            continue
+    return None
+
+
+ALLOWED_CPUS = None      # the affinity mask the process started with (run() records it before binding to the GPU's cores)
+
+
 def cpu_baseline(actions_host, seed, budget_s):
     """Times the CPU oracle (oracle/qttt_oracle.c, a scalar C port of the reference algorithm) on this box's host
     cores, on a bounded sample of the same workload: the recorded steps of a slice of the boards, one slice per thread,
@@ -199,6 +212,9 @@ def cpu_baseline(actions_host, seed, budget_s):
 
     def run_pass(threads, budget, per=None):
         per = per or n // threads
+        # one C call replays `chunk` steps of the slice: ~100 K board-steps, a few ms — so that the clock is looked at often
+        # enough even when the threads outnumber the cores the box lets this job use
+        chunk = max(1, min(T, 100000 // max(per, 1)))
 
         def work(k):
             ob = oracle.OracleBoards(per)
@@ -207,10 +223,12 @@ def cpu_baseline(actions_host, seed, budget_s):
             t_end = time.perf_counter() + budget
             while True:
                 ob.reset()
-                ob.replay(base + 2 * k * per, n, T, seed, 0, k * per, True, scratch)
-                done += per * T
-                if time.perf_counter() > t_end:
-                    return done
+                for t0 in range(0, T, chunk):
+                    tc = min(chunk, T - t0)
+                    ob.replay(base + 2 * (t0 * n + k * per), n, tc, seed, t0, k * per, True, scratch)
+                    done += per * tc
+                    if time.perf_counter() > t_end:
+                        return done
         t0 = time.perf_counter()
         if threads == 1:
             total = work(0)
@@ -219,12 +237,25 @@ def cpu_baseline(actions_host, seed, budget_s):
                 total = sum(ex.map(work, range(threads)))
         dt = time.perf_counter() - t0
         return total / dt, dt, per, total
-    v1, dt1, per1, _ = run_pass(1, budget_s * 0.15, per=n // share)     # one of the share pass's slices
-    v, dt, per, total = run_pass(share, budget_s * 0.6)
-    va, dta, pera, _ = (v, dt, per, total) if nproc == share else run_pass(nproc, budget_s * 0.25)
+    v1, dt1, per1, _ = run_pass(1, budget_s * 0.12, per=n // share)     # one of the share pass's slices
+    v, dt, per, total = run_pass(share, budget_s * 0.5)
+    # the all-cores pass runs on every CPU the process MAY use: the binding to the GPU's own cores (bind_cpu) is lifted
+    # for it and put back afterwards (threads inherit the mask they are started under)
+    bound = os.sched_getaffinity(0)
+    try:
+        if ALLOWED_CPUS and ALLOWED_CPUS != bound:
+            os.sched_setaffinity(0, ALLOWED_CPUS)
+        allowed = len(os.sched_getaffinity(0))
+        va, dta, pera, _ = run_pass(nproc, budget_s * 0.2) if nproc != share else (v, dt, per, total)
+    finally:
+        os.sched_setaffinity(0, bound)
     py = python_interpreter_line(actions_host, seed)
     return {"value": v, "unit": "steps/s", "cores": share, "kind": "port",
             "threads1": v1, "threads_all": va, "threads_all_cores": nproc, "nproc": nproc, "cpu_model": cpu_model(),
+            # what the box lets this job use: the CPUs in its affinity mask and the container's CPU quota ("max" = none;
+            # "1600000 100000" = 16 cores' worth) — with a quota below nproc the all-cores pass is 256 threads sharing
+            # that quota and reads LOWER than the 16-thread pass
+            "cpus_allowed": allowed, "cgroup_cpu_max": cgroup_cpu_max(),
             "python_interpreter_steps_per_s": py,
             "sample": "%d boards x the first %d recorded steps of the same workload (uniform-legal policy, "
                       "auto-reset), replayed from reset %.1f times, %d threads x %d boards, %.1f s of wall time; "
@@ -640,6 +671,8 @@ def run(args):
     n_dev = torch.cuda.device_count()
     if n_dev < 1:
         raise SystemExit("no HIP device visible; bench.py has no CPU path")
+    global ALLOWED_CPUS
+    ALLOWED_CPUS = os.sched_getaffinity(0)
     bind_cpu(n_dev)                  # before anything initialises HIP (device_count() does not)
     affinity = CPU_AFFINITY
     if backend == "nccl" and world > n_dev:

@@ -56,6 +56,7 @@ def test_bench_json_contract_small_batch():
     assert 1e6 < c["threads1"] <= c["value"] * 1.05 and c["nproc"] >= c["cores"] and isinstance(c["cpu_model"], str)
     # ... and the all-host-cores pass (os.cpu_count() threads) beside the GPU's 16-core share
     assert c["threads_all_cores"] == c["nproc"] and c["threads_all"] > c["threads1"]
+    assert 1 <= c["cpus_allowed"] <= c["nproc"] and "cgroup_cpu_max" in c      # why all cores may read lower than the share
     assert "threads_all" in c["sample"] and "threads1" in c["sample"]
     assert "legs" not in d
 

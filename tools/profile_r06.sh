@@ -24,7 +24,11 @@ python3 - "$out/kt_gymdef" > "$out/kernel_trace_gym_default_dispatches.txt" <<'P
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-obs = [i for i, r in enumerate(rows) if "step_kernel" in r["Kernel_Name"] and r["Kernel_Name"].rstrip(">").rstrip().endswith("true, false")]
+import re
+OBS = re.compile(r"step_kernel<\d+, \d+, (?:true|false), (?:true|false), (?:true|false), true, (?:true|false)>")   # template argument 6 = OBS
+is_obs = lambda r: OBS.search(r["Kernel_Name"]) is not None
+short = lambda k: re.sub(r"\(.*$", "", k.replace("void ", "").replace("(anonymous namespace)::", ""))
+obs = [i for i, r in enumerate(rows) if is_obs(r)]
 print("kernel trace of: bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs --mode gym-default  (%d dispatches in all)" % len(rows))
 if obs:
     span = rows[obs[0]:obs[-1] + 1]
@@ -32,11 +36,11 @@ if obs:
     print("dispatches from the first to the last observation-writing step kernel (the timed regions and what lies between them):")
     for k, v in c.most_common():
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in span if r["Kernel_Name"] == k]
-        print("  %6d x %-70s avg %8.1f ns" % (v, k[:70], sum(d) / len(d)))
+        print("  %6d x %-70s avg %8.1f ns" % (v, short(k)[:70], sum(d) / len(d)))
     # inside one timed region: K = 20 consecutive default steps -> consecutive dispatches of the step kernel only
     runs, cur = [], 0
     for r in span:
-        if "step_kernel" in r["Kernel_Name"] and "true, false>" in r["Kernel_Name"]: cur += 1
+        if is_obs(r): cur += 1
         else:
             if cur: runs.append(cur)
             cur = 0
