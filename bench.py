@@ -863,7 +863,7 @@ def run(args):
             bpl, blk = wl.shape                                            # the library's own choice for this batch
             gym = args.mode in ("gym", "gym-default")
             traffic, traffic_fresh = (pmc_traffic_per_launch(B, state_bytes) if args.mode == "replay" else
-                                      pmc_traffic_per_launch(B, state_bytes, "+gym") if gym else (None, None))
+                                      pmc_traffic_per_launch(B, state_bytes, "+" + args.mode) if gym else (None, None))
             what = WHAT[args.mode] % args.fused_steps if args.mode == "random-fused" else WHAT[args.mode]
             out = {
                 "metric": "env_steps_per_sec", "value": value, "unit": "steps/s", "n_gpus": world,
