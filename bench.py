@@ -550,7 +550,10 @@ def row_legs(torch, dev, args, n=1 << 20, K=20, regions=5):
     ni_py, sk = env.node_info(python_key=True), env.state_keys()
     xp, xp_py, ro, enc = env.expand(act, python_key=False), env.expand(act, python_key=True), env.rollout(), env.encode()
     env_in = VecEnv(n, device=dev, seed=args.seed)             # the target of the import row
+    env_rs = VecEnv(n, device=dev, seed=args.seed)             # the target of the reset row
     rows = [
+        # Env.reset with its observation (env.py:55-57), one launch of seven fills: 16 + 30 bytes written per board
+        ("reset_observe", "reset_observe_kernel", lambda: env_rs.reset(copy_obs=False), sb + 30, "hbm (write)"),
         ("observe", "observe_kernel", lambda: env.observ(), sb + 30, "hbm"),
         ("export", "export_kernel", lambda: env.export_boards(out=ex), sb + 37, "hbm"),
         ("import", "import_kernel", lambda: env_in.import_boards(ex["moves"], ex["n_moves"], ex["board"], ex["qmask"], ex["n_q"]),

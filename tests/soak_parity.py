@@ -34,6 +34,10 @@ def one_case(rng, k):
     use_bits = bool(rng.integers(0, 2))
     adversarial = rng.random() < 0.4
     observe = bool(rng.integers(0, 2))
+    # with the observation: the zero-copy form, the DEFAULT step() (fresh tensors, one kernel) checked at once, or the
+    # default step() with every step's tensors KEPT and checked after the last step
+    obs_mode = ["raw", "default", "default_keep"][int(rng.integers(0, 3))] if observe else None
+    kept = []
     seed = int(rng.integers(0, 2**62))
     steps = int(rng.integers(3, 14)) if n < 600000 else int(rng.integers(3, 7))
     per_call = bool(rng.integers(0, 2))               # the launch shape in the calls' own flags, or the process default
@@ -65,8 +69,11 @@ def one_case(rng, k):
             a = torch.from_numpy(a_or).to(env.device)
         bits_np = rng.integers(0, 2, size=n).astype(np.uint8) if use_bits else None
         bits = torch.from_numpy(bits_np).to(env.device) if use_bits else None
-        if observe:
+        if observe and obs_mode == "raw":
             o, reward, term = env.step_observe_raw(a, bits)
+        elif observe:
+            o, reward, term, trunc, info = env.step(a, bits)
+            assert info == {} and trunc.shape == (n,)
         elif not adversarial and not use_bits and t % 3 == 2:      # policy + step in one kernel: the same step
             played = torch.empty_like(a)
             reward, term = env.step_random(actions_out=played)
@@ -78,9 +85,17 @@ def one_case(rng, k):
         assert np.array_equal(npy(term).astype(np.uint8), t_or), ("terminated", t)
         if observe:
             classical, q1, l1, q2, l2, turn = ob.observe()
-            for name, ref in (("classical", classical), ("q_states_p1", q1), ("q_states_p1_len", l1),
-                              ("q_states_p2", q2), ("q_states_p2_len", l2), ("turn", turn)):
+            refs = (("classical", classical), ("q_states_p1", q1), ("q_states_p1_len", l1),
+                    ("q_states_p2", q2), ("q_states_p2_len", l2), ("turn", turn))
+            for name, ref in refs:
                 assert np.array_equal(npy(o[name]), ref), (name, t)
+            if obs_mode == "default_keep":
+                kept.append((t, o, reward, term, refs, r_or, t_or))
+    for t, o, reward, term, refs, r_or, t_or in kept:        # nothing the caller kept was written again
+        for name, ref in refs:
+            assert np.array_equal(npy(o[name]), ref), ("kept", name, t)
+        assert np.array_equal(npy(reward).view(np.uint32), r_or.view(np.uint32)), ("kept reward", t)
+        assert np.array_equal(npy(term).astype(np.uint8), t_or), ("kept terminated", t)
     ex = {kk: npy(v) for kk, v in env.export_boards().items()}
     assert np.array_equal(ex["board"], ob.board) and np.array_equal(ex["moves"], ob.moves)
     assert np.array_equal(ex["n_moves"], ob.n_moves) and np.array_equal(ex["qmask"].view(np.uint16), ob.qmask)
@@ -89,7 +104,7 @@ def one_case(rng, k):
     w1, w2 = ob.check_win()
     assert np.array_equal(npy(p1), w1) and np.array_equal(npy(p2), w2)
     return dict(case=k, n=n, offset=off, shape=shape, per_call=per_call, auto_reset=auto_reset, bits=use_bits,
-                adversarial=adversarial, observe=observe, fused_plies=fused, steps=steps)
+                adversarial=adversarial, observe=obs_mode, fused_plies=fused, steps=steps)
 
 
 def rows_case(rng, k):
