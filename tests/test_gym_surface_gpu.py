@@ -239,3 +239,22 @@ def test_step_returns_copies_by_default_and_takes_non_contiguous_inputs(golden):
     o_b, _, _, _, _ = raw.step(a1, torch.from_numpy(bits[:, 1].copy()).cuda(), copy_obs=False)
     assert all(o_a[k].data_ptr() == o_b[k].data_ptr() for k in o_a)                                      # the env's own buffers
     assert np.array_equal(_np(o_b["classical"]), golden["board"][:, 1])
+
+
+def test_zero_boards_and_one_board():
+    """the edges of the batch size: an empty environment steps and resets without a launch; one board is one board"""
+    from qtttgym_amd import VecEnv
+    e0 = VecEnv(0)
+    obs, info = e0.reset()
+    assert obs["classical"].shape == (0, 9) and info == {}
+    o, r, tm, tr, info = e0.step(torch.empty((0, 2), dtype=torch.uint8, device="cuda"))
+    assert r.shape == (0,) and tm.shape == (0,) and o["q_states_p1"].shape == (0, 5, 2) and o["turn"].shape == (0,)
+    e1 = VecEnv(1)
+    obs, _ = e1.reset()
+    assert obs["classical"].tolist() == [[-1] * 9] and obs["turn"].tolist() == [0]
+    o, r, tm, tr, info = e1.step(torch.tensor([[0, 1]], dtype=torch.uint8, device="cuda"))
+    assert o["q_states_p1"][0, 0].tolist() == [0, 1] and int(o["q_states_p1_len"]) == 1 and int(o["turn"]) == 1     # K1, SURVEY Appendix A
+    o2, r2, tm2, _, _ = e1.step(torch.tensor([[1, 0]], dtype=torch.uint8, device="cuda"), torch.tensor([0], dtype=torch.uint8, device="cuda"))
+    assert o2["classical"][0].tolist() == [1, 0, -1, -1, -1, -1, -1, -1, -1] and int(o2["turn"]) == 0
+    assert o["classical"][0].tolist() == [-1] * 9                                      # step 1's tensors are still step 1's
+    assert r2.view(torch.int32).item() == -(2 ** 31) and not bool(tm2)                 # -0.0 (env.py:49)
