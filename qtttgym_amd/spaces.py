@@ -35,8 +35,31 @@ def _find_ray_repeated(gspaces):
         return None
 
 
+class PlainEnvBase:
+    """What a gym loop written against the reference touches on `gymnasium.Env` besides reset / step / render (the
+    reference's Env inherits them, env.py:15): close(), `unwrapped`, the context-manager form, and the class attributes
+    wrappers read.  Used as Env's base when gymnasium is not importable."""
+    metadata = {"render_modes": []}
+    render_mode = None
+    spec = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
 GYMNASIUM, GYM_SPACES = _find_gymnasium()
-GYM_ENV_BASE = GYMNASIUM.Env if GYMNASIUM is not None else object
+GYM_ENV_BASE = GYMNASIUM.Env if GYMNASIUM is not None else PlainEnvBase
 RAY_REPEATED = _find_ray_repeated(GYM_SPACES) if GYMNASIUM is not None else None
 
 

@@ -216,6 +216,24 @@ class VecEnv:
             actions = torch.where((a < 0) | (a > 255), torch.full_like(a, 255), a).to(torch.uint8)
         return actions.to(self.device).contiguous()
 
+    # what gym-style callers touch besides reset / step (gymnasium.vector's names for the per-board spaces; the reference's
+    # Env declares the per-board spaces, env.py:19-25, and those are what action_space / observation_space hold here)
+    @property
+    def single_action_space(self):
+        return self.action_space
+
+    @property
+    def single_observation_space(self):
+        return self.observation_space
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def close(self):
+        """Drops the pooled output sets (the state and the tensors a caller holds stay valid)."""
+        self._pool, self._pool_i = [], 0
+
     def synchronize(self):
         """torch.cuda.synchronize(device) for a process that also uses the single-board façades (Board, Env): their
         mailbox wave (include/qttt.h, qttt_board_op_host) is asked to leave first, so the device-wide wait has nothing

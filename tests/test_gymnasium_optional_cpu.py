@@ -107,7 +107,7 @@ def test_placeholders_parked_in_sys_modules_are_not_mistaken_for_gymnasium():
     """tests/golden/ref_shim.py parks empty `gymnasium` / `ray` modules in sys.modules to import the reference: this
     package must not take those for the libraries (they have no spaces.Space)."""
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import ref_shim; ref_shim._install_placeholders(); "
-            "from qtttgym_amd import Env, spaces as qs; assert qs.GYMNASIUM is None and Env.__mro__[1] is object; "
+            "from qtttgym_amd import Env, spaces as qs; assert qs.GYMNASIUM is None and Env.__mro__[1] is qs.PlainEnvBase; "
             "o = qs.reference_observation_space(); assert type(o) is qs.Dict and o['q_states_p1'].max_len == 5; print('ok')"
             % (ROOT, os.path.join(ROOT, "tests", "golden")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
@@ -120,5 +120,9 @@ def test_without_gymnasium_the_stand_ins_are_used():
         import pytest
         pytest.skip("gymnasium is installed here")
     from qtttgym_amd import Env, spaces as qs
-    assert qs.GYMNASIUM is None and qs.GYM_ENV_BASE is object and Env.__mro__ == (Env, object)
+    assert qs.GYMNASIUM is None and qs.GYM_ENV_BASE is qs.PlainEnvBase and Env.__mro__ == (Env, qs.PlainEnvBase, object)
     assert type(qs.reference_action_space()) is qs.Tuple and type(qs.reference_observation_space()) is qs.Dict
+    # what a gym loop touches on the base class besides reset / step (the reference inherits it from gymnasium.Env)
+    with Env() as env:
+        assert env.unwrapped is env and env.render_mode is None and env.metadata == {"render_modes": []} and env.spec is None
+    env.close()
