@@ -122,15 +122,18 @@ inline int launch_status() {
 
 // A hint: the single-record mailbox wave (board_mailbox, below) MAY be resident.  It holds one wave slot of one CU, so a
 // launch that fills the chip exactly runs a second partial round beside it (+1.4 us at 1 M boards,
-// profiles/r05/keepwarm_probe.txt): such launches ask it to leave first (it is gone within one poll, before the
-// launch's workgroups are placed).  One relaxed load when no wave is resident.
+// profiles/r05/keepwarm_probe.txt): such launches ask it to leave first (it is gone within one poll).  One relaxed load
+// per launch when no wave is resident.  (What is NOT done from here: querying the mailbox's stream so that the runtime
+// retires the finished kernel.  A finished mailbox kernel nobody has queried leaves the launches of other streams
+// 0.05 - 0.4 us longer for a while — tools/probes/mailbox_rest_delta_probe.py — and one hipStreamQuery after the wave has
+// said it left removes most of that, which qttt_board_mailbox_retire(1) does; but the query returns "not ready" for a few
+// microseconds after the wave's last store, and repeating it from the launch path cost the launches 0.4 - 1.0 us each:
+// measured, profiles/r06/mailbox_rest_delta_probe_query_from_the_launch_path.txt, not adopted.)
 std::atomic<bool> g_mailbox_resident{false};
 constexpr int64_t CHIP_FILLING_BOARDS = 512 * 1024;
-inline void retire_mailbox_for(int64_t n) {
-    if (n >= CHIP_FILLING_BOARDS && g_mailbox_resident.load(std::memory_order_relaxed)) {
-        static const bool keep = [] { const char *e = getenv("QTTT_BOARD_MAILBOX_KEEP"); return e && atoi(e) != 0; }();
-        if (!keep) (void)qttt_board_mailbox_retire(0);       // (QTTT_BOARD_MAILBOX_KEEP=1: A/B diagnostics of this very rule)
-    }
+void mailbox_housekeeping(hipStream_t user_stream);     // (defined beside BoardMailbox)
+inline void retire_mailbox_for(int64_t n, void *stream) {
+    if (n >= CHIP_FILLING_BOARDS && g_mailbox_resident.load(std::memory_order_relaxed)) mailbox_housekeeping((hipStream_t)stream);
 }
 
 }  // namespace
@@ -249,7 +252,7 @@ static int launch_step(void *state, uint8_t *actions, const uint8_t *bits, uint6
     if (n == 0) return 0;
     if (!state || !reward || !terminated || (!sample && !actions)) return QTTT_ERR_NULL;
     if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;   // actions are accessed as u16 pairs
-    retire_mailbox_for(n);
+    retire_mailbox_for(n, stream);
     Planes p = planes(state, n);
     // with a device-side step counter the kernel makes the key itself: it gets the offset and the id fold
     const u64 key = step_ctr ? ((u64)step_idx << 32) : launch_key(seed, step_idx);
@@ -405,7 +408,7 @@ int qttt_step_many(void *state, const uint8_t *actions, const uint8_t *bits, uin
         if (board_offset < 0) return QTTT_ERR_SIZE;
         if (!state || !actions || !reward || !terminated) return QTTT_ERR_NULL;
         if ((uintptr_t)actions & 1u) return QTTT_ERR_ACTION;
-        retire_mailbox_for(n);
+        retire_mailbox_for(n, stream);
         Planes p = planes(state, n);
         const bool ar = (flags & QTTT_FLAG_AUTO_RESET) != 0;
         const u32 hi_fold = (u32)(first >> 32) * 0x9E3779B9u;
@@ -448,7 +451,7 @@ int qttt_step_random_many(void *state, uint64_t seed, uint32_t step_idx0, int64_
     if (n == 0 || n_steps == 0) return 0;
     if (!state || (reward == nullptr) != (terminated == nullptr)) return QTTT_ERR_NULL;
     if (((uintptr_t)actions_out & 1u) || ((uintptr_t)reward & 3u) || ((uintptr_t)returns & 3u)) return QTTT_ERR_ACTION;
-    retire_mailbox_for(n);
+    retire_mailbox_for(n, stream);
     Planes p = planes(state, n);
     hipStream_t s = (hipStream_t)stream;
     uint16_t *a16 = reinterpret_cast<uint16_t *>(actions_out);
@@ -635,27 +638,44 @@ struct BoardMailbox {
         volatile u32 *w = reinterpret_cast<volatile u32 *>(slot_in);
         w[3] = v; w[7] = v; w[11] = v; w[15] = v;
     }
-    // the wave was asked to leave: wait until it has said so (its next poll: a few us; bounded)
+    bool has_left() { return *static_cast<volatile u32 *>(exited) == generation; }
+    // the wave was asked to leave: wait until it has said so (its next poll: a few us; bounded), then give the runtime ONE
+    // chance to retire the finished kernel here rather than beside the caller's next launches (see g_mailbox_resident)
     void await_exit() {
-        volatile u32 *gone = exited;
         const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
-        for (unsigned spin = 1; *gone != generation; ++spin)
+        bool gone = has_left();
+        for (unsigned spin = 1; !gone; ++spin, gone = has_left())
             if ((spin & 1023u) == 0u && std::chrono::steady_clock::now() > give_up) break;   // (it then leaves by its idle exit)
         alive = leaving = false;
+        g_mailbox_resident.store(false, std::memory_order_relaxed);
+        if (gone) { (void)hipStreamQuery(stream); (void)hipGetLastError(); }
     }
     // 0 = a resident wave was asked to leave (or none was resident); it is gone within a poll (a few us)
     int retire(bool wait) {
         std::lock_guard<std::mutex> g(mu);
-        g_mailbox_resident.store(false, std::memory_order_relaxed);
-        if (!on || !alive) return 0;
-        volatile u32 *gone = exited;
-        if (*gone == generation) { alive = leaving = false; return 0; }
+        if (!on || !alive) { g_mailbox_resident.store(false, std::memory_order_relaxed); return 0; }
+        if (has_left()) { alive = leaving = false; g_mailbox_resident.store(false, std::memory_order_relaxed); return 0; }
         if (!leaving) {
             write_numbers(MBOX_LEAVE);
             leaving = true;
         }
         if (wait) await_exit();
         return 0;
+    }
+    // From the step entries, in front of a launch that fills the chip (never blocks, never calls into the runtime): ask a
+    // resident wave to leave.
+    void housekeeping() {
+        std::unique_lock<std::mutex> g(mu, std::try_to_lock);
+        if (!g.owns_lock()) return;                              // a Board call is in flight on another thread: its business
+        if (!on || !alive) { g_mailbox_resident.store(false, std::memory_order_relaxed); return; }
+        if (has_left()) { alive = leaving = false; g_mailbox_resident.store(false, std::memory_order_relaxed); return; }
+        if (!leaving) {
+            static const bool keep = [] { const char *e = getenv("QTTT_BOARD_MAILBOX_KEEP"); return e && atoi(e) != 0; }();
+            if (keep) return;                                    // (QTTT_BOARD_MAILBOX_KEEP=1: A/B diagnostics of this very rule)
+            write_numbers(MBOX_LEAVE);
+            leaving = true;
+        }
+        g_mailbox_resident.store(false, std::memory_order_relaxed);   // asked once: the later launches have nothing to do here
     }
     // 0 = answered (out filled), 1 = not served: use the launch path
     int call(const void *rec_in, void *rec_out) {
@@ -694,6 +714,7 @@ BoardMailbox &board_mailbox() {
     static BoardMailbox m;
     return m;
 }
+void mailbox_housekeeping(hipStream_t) { board_mailbox().housekeeping(); }
 }  // namespace
 extern "C" {
 
