@@ -521,14 +521,31 @@ def gym_default_leg(torch, dev, args, n=1 << 20, K=100, W=10):
     env, a = w.env, w.actions[W]
     dev_paced, eager = time_calls(torch, dev, lambda: env.step(a), 50, 8)
     dp = median(dev_paced)
+    # the same loop with VecEnv(output_pool=4): output sets the caller has dropped are re-used instead of allocated
+    from qtttgym_amd import VecEnv, vec_env
+    pooled = VecEnv(n, device=dev, seed=args.seed, auto_reset=True, output_pool=4)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pooled_us = []
+    for _ in range(8):
+        for t in range(W):
+            out = pooled.step(w.actions[t])
+        e0.record()
+        for t in range(W, W + K):
+            out = pooled.step(w.actions[t])
+        e1.record()
+        torch.cuda.synchronize(dev)
+        pooled_us.append(e0.elapsed_time(e1) * 1e3 / K)
+    del pooled, out
     leg = {"name": "gym_default_1048576_boards", "boards": n, "mode": "gym-default", "kernel": kernel_label("gym-default", *w.shape, boards=n),
-           "call": "VecEnv.step(actions) -> (obs, reward, terminated, truncated, info), fresh tensors every call (copy_obs=True, the default)",
+           "call": "VecEnv.step(actions) -> (obs, reward, terminated, truncated, info), fresh tensors every call (copy_obs=True, output_pool=0: the defaults)",
            "steps": K, "warmup": W, "regions": R,
            "us_per_step": us, "best_region_us_per_step": ev_min / K * 1e6,
            "device_paced_us_per_step": dp, "us_per_python_call_idle_stream": median(eager),
            "timing": "us_per_step: region clock (W launches queued ahead of K timed Python calls); device_paced: hipGraph of %d "
                      "default step() calls replayed; us_per_python_call_idle_stream: K eager calls, events around them" % GRAPH_LAUNCHES,
-           "steps_per_s": n * K / ev, "output_sets_in_use": len(env._pool),
+           "steps_per_s": n * K / ev, "outputs": "one fresh allocation per call (torch's caching allocator), carved into the eight tensors by "
+           + ("qtttgym_amd/_fastviews.so" if vec_env._fastviews is not None else "Python-level torch calls (_fastviews.so not built)"),
+           "us_per_step_with_output_pool_4": median(pooled_us),
            "algorithmic_bytes_per_board_step": w.algo_bytes, "achieved_GBps": w.algo_bytes * n / (dp * 1e-6) / 1e9,
            "frac": w.algo_bytes * n / (dp * 1e-6) / 1e9 / HBM_PEAK_GBS, "frac_region_clock": w.algo_bytes * n / (ev / K) / 1e9 / HBM_PEAK_GBS,
            "bound": "hbm", "replay_matches_recording": w.replay_ok}

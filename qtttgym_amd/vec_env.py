@@ -24,51 +24,67 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-# Re-using an output set needs two counters torch keeps but does not document (the storage's and the TensorImpl's use
-# counts); without either, every default step() / reset() simply allocates its outputs (same results, ~25 us more host time)
+def _layout(n):
+    """Byte offsets of the eight tensors a default step() returns inside their one allocation (reward f32[n], terminated
+    bool[n], q_states_p1 u8[n,5,2], q_states_p1_len u8[n], q_states_p2 u8[n,4,2], q_states_p2_len u8[n], classical i8[n,9],
+    turn u8[n]; every one starts on a 512-byte boundary) and, last, the allocation's size.  csrc/fastviews.cpp has the
+    same arithmetic (checked by tests/test_fastviews_cpu.py)."""
+    offs, total = [], 0
+    for b in (4 * n, n, 10 * n, n, 8 * n, n, 9 * n, n):
+        offs.append(total)
+        total += (b + 511) // 512 * 512
+    return tuple(offs) + (total,)
+
+
+def _carve_py(n, dev):
+    """One allocation from torch's caching allocator and the eight tensors as views of it: (tensors, address)."""
+    o = _layout(n)
+    buf = torch.empty(o[8], dtype=torch.uint8, device=dev)
+    cut = lambda k, shape, stride: torch.as_strided(buf, shape, stride, o[k])
+    return ([cut(0, (4 * n,), (1,)).view(torch.float32), cut(1, (n,), (1,)).view(torch.bool),
+             cut(2, (n, 5, 2), (10, 2, 1)), cut(3, (n,), (1,)), cut(4, (n, 4, 2), (8, 2, 1)), cut(5, (n,), (1,)),
+             cut(6, (n, 9), (9, 1)).view(torch.int8), cut(7, (n,), (1,))], buf.data_ptr())
+
+
+# The same in C++ when qtttgym_amd/_fastviews.so is built (csrc/fastviews.cpp, __graft_entry__.build()): ~2 us of host
+# time per call instead of ~12 for the twelve torch calls above — what lets the default step() take a FRESH allocation
+# every call and still stay ahead of the kernel at 1 M boards.
+try:
+    from . import _fastviews
+    _carve = _fastviews.carve
+except ImportError:
+    _fastviews = None
+    _carve = _carve_py
+
+# Re-using an output set (VecEnv(output_pool=N), opt-in) needs two counters torch keeps but does not document (the
+# storage's and the TensorImpl's use counts); without either, the pool is off and every call allocates
 _storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
 if not hasattr(torch.Tensor, "_use_count"):
     _storage_use_count = None
 _is_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None) or torch.cuda.is_current_stream_capturing
-_OBS_KEYS = ("q_states_p1", "q_states_p1_len", "q_states_p2", "q_states_p2_len", "classical", "turn")
 
 
 class _OutputSet:
-    """What ONE default step() / reset() returns — reward f32[N], terminated bool[N] and the six observation tensors
-    (env.py:46,53,68-85) — as views of ONE allocation from torch's caching allocator (each view starts on a 512-byte
-    boundary), plus the qttt_env record that points the step kernel at them: the kernel writes the caller's fresh
-    tensors directly, nothing is copied afterwards.
+    """VecEnv(output_pool=N > 0): one step's outputs kept for RE-USE — for loops whose host time per step matters more
+    than plain allocator semantics (a pooled step() costs ~2 us of host time less than a fresh allocation; without
+    _fastviews.so ~10 us less).
 
     A set is handed out again only when nothing outside the environment can still see it, which `free()` checks
     exactly: no Python reference to any of its eight tensors beyond the environment's own (sys.getrefcount), no C++
     reference to their TensorImpls (autograd, DLPack: Tensor._use_count) and no other tensor on their storage (views,
-    .detach(), .data: the storage's use count).  A caller that rebinds `obs, reward, terminated, ... = env.step(a)`
-    every step therefore alternates between two sets with no allocation and no view construction per step; a caller
-    that keeps every observation gets a new allocation every step.  Either way the tensors of step t are never
-    written again while the caller can reach them."""
-    __slots__ = ("t", "rec", "rec_ref", "stream", "_st", "_base")
+    .detach(), .data: the storage's use count) — and only on the stream that wrote it last.  A caller that rebinds
+    `obs, reward, terminated, ... = env.step(a)` every step alternates between two sets with no allocation at all; a
+    caller that keeps every observation gets a new allocation every step.  What the pool does NOT see: work queued on
+    ANOTHER stream that reads a tensor the caller has already dropped — Tensor.record_stream protects an allocation of
+    the caching allocator, not a pooled set.  That is why the pool is opt-in and the default step() allocates."""
+    __slots__ = ("t", "base", "stream", "_st", "_base")
 
     def __init__(self, env):
-        n, dev = env.num_envs, env.device
-        seg = lambda nbytes: (nbytes + 511) // 512 * 512
-        sizes = (4 * n, n, 10 * n, n, 8 * n, n, 9 * n, n)      # reward, terminated, then the _OBS_KEYS order
-        offs, total = [], 0
-        for b in sizes:
-            offs.append(total)
-            total += seg(b)
-        buf = torch.empty(total, dtype=torch.uint8, device=dev)
-        cut = lambda k, shape, stride: torch.as_strided(buf, shape, stride, offs[k])
-        self.t = (cut(0, (4 * n,), (1,)).view(torch.float32), cut(1, (n,), (1,)).view(torch.bool),
-                  cut(2, (n, 5, 2), (10, 2, 1)), cut(3, (n,), (1,)), cut(4, (n, 4, 2), (8, 2, 1)), cut(5, (n,), (1,)),
-                  cut(6, (n, 9), (9, 1)).view(torch.int8), cut(7, (n,), (1,)))
-        base = buf.data_ptr()
-        p = [base + o for o in offs]
-        self.rec = _native.EnvRecord(n=n, reward=p[0], terminated=p[1], q_p1=p[2], q_p1_len=p[3], q_p2=p[4],
-                                     q_p2_len=p[5], classical=p[6], turn=p[7])
-        self.rec_ref = ctypes.byref(self.rec)
+        t, self.base = _carve(env.num_envs, env.device)
+        self.t = tuple(t)
+        del t
         self.stream = None
-        self._st = buf.untyped_storage() if _storage_use_count is not None else None
-        del buf, cut
+        self._st = self.t[0].untyped_storage() if _storage_use_count is not None else None
         self._base = self._probe() if self._st is not None else None
 
     def _probe(self):
@@ -81,11 +97,6 @@ class _OutputSet:
 
     def free(self):
         return self._st is not None and self._probe() == self._base
-
-    def obs(self):
-        t = self.t
-        return {"q_states_p1": t[2], "q_states_p1_len": t[3], "q_states_p2": t[4], "q_states_p2_len": t[5],
-                "classical": t[6], "turn": t[7]}
 
 
 def _check_out(t, dtype, shape, dev, what):
@@ -100,7 +111,7 @@ class VecEnv:
     like the reference's mutable Env (env.py:15)."""
 
     def __init__(self, num_envs, device="cuda", seed=0, auto_reset=False, board_offset=0, launch_shape=None,
-                 output_pool=4):
+                 output_pool=0):
         self.num_envs = int(num_envs)
         if self.num_envs < 0:
             raise ValueError("num_envs must be >= 0")
@@ -130,7 +141,8 @@ class VecEnv:
             self._terminated = torch.empty(n, dtype=torch.bool, device=self.device)
             self._truncated = torch.zeros(n, dtype=torch.bool, device=self.device)  # env.py:52
         self._obs = None
-        # default step() / reset(): at most this many output sets are kept for re-use (0: a new allocation per call)
+        # default step() / reset(): a fresh allocation per call (0, the default), or at most this many output sets kept
+        # for re-use (_OutputSet)
         self._pool, self._pool_i, self._pool_max = [], 0, max(0, int(output_pool))
         self._bind_outputs()
         self.reset_raw()
@@ -181,6 +193,10 @@ class VecEnv:
                                       terminated=self._p_term)
         self._rec_ref = ctypes.byref(self._rec)
         self._env_step = self._lib.qttt_env_step
+        # the record a default step() / reset() points at ITS output tensors (read by the library during the call only)
+        self._out_offs = _layout(self.num_envs)
+        self._rec_out = _native.EnvRecord(n=self.num_envs)
+        self._rec_out_ref = ctypes.byref(self._rec_out)
 
     def _record(self):
         """The qttt_env record with the fields a caller may have changed since the last step."""
@@ -243,7 +259,7 @@ class VecEnv:
 
     # ------------------------------------------------------------------ gym surface
     def reset_raw(self, seed=None):
-        """Fresh boards without building the observation (one memset on the stream)."""
+        """Fresh boards without building the observation (one launch of zero stores on the stream)."""
         if seed is not None:
             self.seed = int(seed)
         self.step_idx = 0                         # (the device counter's fill is ordered on the stream like the memset)
@@ -252,33 +268,41 @@ class VecEnv:
                           "qttt_reset")
 
     def _fresh_outputs(self):
-        """An output set nobody else can see: a pooled one that is free (see _OutputSet), else a new allocation.
-        Inside a hipGraph capture every call allocates (from the graph's private pool, which lives as long as the
-        graph): a captured launch keeps writing where it was captured, so its buffers must never be handed out again."""
-        stream = self._stream()
+        """The eight tensors of one default step() / reset() — reward, terminated, q_states_p1, q_states_p1_len,
+        q_states_p2, q_states_p2_len, classical, turn — which nobody else holds, and self._rec_out pointing at them.
+        Default: ONE new allocation from torch's caching allocator per call, carved into the eight views (csrc/fastviews.cpp
+        when built): plain allocator semantics, nothing is ever re-used behind the caller's back.  With output_pool=N: a
+        pooled set that is free (_OutputSet), else a new one.  Inside a hipGraph capture every call allocates (from the
+        graph's private pool, which lives as long as the graph): a captured launch keeps writing where it was captured."""
         if self._pool_max and not _is_capturing():
+            stream = self._stream()
             pool, i = self._pool, self._pool_i
             k = len(pool)
+            s = None
             for _ in range(k):
                 i = i + 1 if i + 1 < k else 0
-                s = pool[i]
+                c = pool[i]
                 # (re-use only on the stream that wrote it last: the same rule as torch's caching allocator)
-                if s.stream == stream and s.free():
-                    self._pool_i = i
-                    return s
-            s = _OutputSet(self)
-            s.stream = stream
-            if k < self._pool_max:
-                pool.append(s)
-                self._pool_i = k
-            else:                                   # every set is still held by the caller: forget the oldest one
-                i = self._pool_i + 1 if self._pool_i + 1 < k else 0
-                pool[i] = s
-                self._pool_i = i
-            return s
-        s = _OutputSet(self)
-        s.stream = stream
-        return s
+                if c.stream == stream and c.free():
+                    s = c
+                    break
+            if s is None:
+                s = _OutputSet(self)
+                s.stream = stream
+                if k < self._pool_max:
+                    pool.append(s)
+                    i = k
+                else:                               # every set is still held by the caller: forget the oldest one
+                    i = self._pool_i + 1 if self._pool_i + 1 < k else 0
+                    pool[i] = s
+            self._pool_i = i
+            t, base = s.t, s.base
+        else:
+            t, base = _carve(self.num_envs, self.device)
+        r, o = self._rec_out, self._out_offs
+        r.reward, r.terminated, r.q_p1, r.q_p1_len = base, base + o[1], base + o[2], base + o[3]
+        r.q_p2, r.q_p2_len, r.classical, r.turn = base + o[4], base + o[5], base + o[6], base + o[7]
+        return t
 
     def reset(self, *, seed=None, options=None, copy_obs=True):
         """env.py:55-57: fresh boards and their observation, ONE kernel (qttt_reset_observe); `seed`/`options`
@@ -290,8 +314,10 @@ class VecEnv:
             self.seed = int(seed)
         self.step_idx = 0
         if copy_obs:
-            s = self._fresh_outputs()
-            r, obs = s.rec, s.obs()
+            t = self._fresh_outputs()
+            r = self._rec_out
+            obs = {"q_states_p1": t[2], "q_states_p1_len": t[3], "q_states_p2": t[4], "q_states_p2_len": t[5],
+                   "classical": t[6], "turn": t[7]}
         else:
             obs = self._obs_buffers()
             r = self._rec
@@ -371,8 +397,8 @@ class VecEnv:
         else (the step kernel writes the observation from the registers it holds, straight into the tensors returned).
         copy_obs=True (default): the returned observation, reward and terminated are tensors nobody else holds — as
         the reference's Env.step builds new lists every call (env.py:46,68-85), a gym caller may keep (obs, next_obs)
-        pairs, or every observation of an episode; they are never written again while the caller can reach them
-        (_OutputSet).  copy_obs=False returns the environment's own buffers, overwritten by the next such step() /
+        pairs, or every observation of an episode: one fresh allocation per call, carved into the eight tensors
+        (_fresh_outputs; VecEnv(output_pool=N) re-uses sets the caller has dropped instead).  copy_obs=False returns the environment's own buffers, overwritten by the next such step() /
         observ() — = step_observe_raw."""
         dev = self.state.device
         if not (torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == dev
@@ -386,16 +412,15 @@ class VecEnv:
             return obs, reward, terminated, self._truncated, {}
         if bits is not None and bits.numel() != self.num_envs:
             raise ValueError("bits must be a contiguous uint8 device tensor of shape (N,)")
-        s = self._fresh_outputs()
-        r, own = s.rec, self._rec
+        t = self._fresh_outputs()
+        r = self._rec_out
         r.state = self.state.data_ptr()
-        r.board_offset, r.seed, r.flags, r.step_counter = self.board_offset, self.seed, self._flags(), own.step_counter
-        rc = self._launch(self._env_step, s.rec_ref, actions.data_ptr(), _ptr(bits), self._step_host,
-                          _native.ENV_STEP_OBSERVE, s.stream)
+        r.board_offset, r.seed, r.flags, r.step_counter = self.board_offset, self.seed, self._flags(), self._rec.step_counter
+        rc = self._launch(self._env_step, self._rec_out_ref, actions.data_ptr(), _ptr(bits), self._step_host,
+                          _native.ENV_STEP_OBSERVE, self._stream())
         if rc:
             _native.check(rc, "qttt_step_observe")
         self._advance(1)
-        t = s.t
         return ({"q_states_p1": t[2], "q_states_p1_len": t[3], "q_states_p2": t[4], "q_states_p2_len": t[5],
                  "classical": t[6], "turn": t[7]}, t[0], t[1], self._truncated, {})
 
@@ -597,7 +622,7 @@ class VecEnv:
             env._terminated = torch.empty(n, dtype=torch.bool, device=env.device)
             env._truncated = torch.zeros(n, dtype=torch.bool, device=env.device)
         env._obs = None
-        env._pool, env._pool_i, env._pool_max = [], 0, 4
+        env._pool, env._pool_i, env._pool_max = [], 0, 0
         env._bind_outputs()
         return env
 

@@ -2,11 +2,13 @@
 `obs, info = env.reset()` as the reference's Env returns them (env.py:34-57): new objects every call (env.py:46,68-85
 builds fresh lists), ONE kernel per call, nothing copied afterwards.  What is checked here:
   * bit-exact against the reference's recorded traces while the caller keeps EVERY step's tensors (none is ever
-    written again), while it keeps (obs, next_obs) pairs, and while it rebinds (then two output sets alternate);
+    written again), while it keeps (obs, next_obs) pairs, and while it rebinds — with the default (one fresh allocation
+    from torch's caching allocator per call, carved by csrc/fastviews.cpp) and with VecEnv(output_pool=N) (sets the
+    caller has dropped are re-used: then two sets alternate and nothing is allocated);
   * a default step() / reset() enqueues exactly one kernel and nothing else (the call captured into a hipGraph, the
     graph's nodes listed by the HIP runtime: tests/hip_graph_nodes.py);
-  * anything that can still see a set's memory (a view, a detached alias, a DLPack capsule, the dict) keeps it from
-    being handed out again; another stream gets another set."""
+  * with the pool: anything that can still see a set's memory (a view, a detached alias, a DLPack capsule, the dict)
+    keeps it from being handed out again; another stream gets another set."""
 import numpy as np
 import pytest
 import torch
@@ -57,12 +59,16 @@ def test_every_step_kept_and_checked_at_the_end(golden):
     assert len(ptrs) == T + 1                                           # T + 1 different allocations
 
 
-def test_step_t_is_intact_after_step_t_plus_1_and_a_rebinding_caller_allocates_nothing(golden):
+@pytest.mark.parametrize("pool", [0, 4])
+def test_step_t_is_intact_after_step_t_plus_1_and_a_rebinding_caller_allocates_nothing(golden, pool):
     """(obs, next_obs) pairs: step t's tensors are unchanged after step t + 1 (and t + 2).  A caller that rebinds its
-    names every step is served from two or three output sets in turn: no allocation per step."""
-    from qtttgym_amd import VecEnv
+    names every step: with output_pool=4 it is served from two or three output sets in turn, not one allocator call per
+    step; with the default (a fresh allocation per call) the allocator recycles the blocks the caller dropped — the
+    memory in use does not grow."""
+    from qtttgym_amd import VecEnv, vec_env
     E, T = golden["bits"].shape
-    env = VecEnv(E)
+    env = VecEnv(E, output_pool=pool)
+    assert vec_env._fastviews is not None            # qtttgym_amd/_fastviews.so is built and in use on the box
     obs, _ = env.reset()
     seen = set()
     prev = None
@@ -73,12 +79,18 @@ def test_step_t_is_intact_after_step_t_plus_1_and_a_rebinding_caller_allocates_n
         _check_step(golden, t, nxt[0], nxt[1], nxt[2])
         prev = nxt                                                       # the set of step t-1 is released HERE
         seen.add(nxt[1].data_ptr())
-    assert len(seen) <= 3 and len(env._pool) <= 3, (len(seen), len(env._pool))
     a, b = _inputs(golden, 0)
-    before = torch.cuda.memory_stats()["allocation.all.allocated"]
+    stats = torch.cuda.memory_stats()
+    calls, in_use = stats["allocation.all.allocated"], stats["allocated_bytes.all.current"]
     for t in range(50):
         obs, reward, term, trunc, info = env.step(a, b)
-    assert torch.cuda.memory_stats()["allocation.all.allocated"] == before     # not one allocator call in 50 steps
+    stats = torch.cuda.memory_stats()
+    if pool:
+        assert len(seen) <= 3 and len(env._pool) <= 3, (len(seen), len(env._pool))
+        assert stats["allocation.all.allocated"] == calls                     # not one allocator call in 50 steps
+    else:
+        assert env._pool == [] and stats["allocation.all.allocated"] == calls + 50    # one allocation per step, exactly
+        assert stats["allocated_bytes.all.current"] <= in_use + 2 * (34 * E + 8 * 512)    # ... and at most two alive
 
 
 def test_default_step_and_reset_enqueue_exactly_one_kernel():
@@ -86,8 +98,8 @@ def test_default_step_and_reset_enqueue_exactly_one_kernel():
     hipGraph holds exactly ONE node, a kernel (no memset, no copy) — with hashed and with explicit collapse bits, at a small and at the
     headline batch size; reset() likewise (qttt_reset_observe); the zero-copy forms too."""
     from qtttgym_amd import VecEnv
-    for n in (4096, 1 << 20):
-        env = VecEnv(n, seed=3, auto_reset=True)
+    for n, pool in ((4096, 0), (1 << 20, 0), (4096, 3)):
+        env = VecEnv(n, seed=3, auto_reset=True, output_pool=pool)
         a = env.sample_actions()
         bits = torch.zeros(n, dtype=torch.uint8, device="cuda")
         assert kernels_enqueued(lambda: env.step(a)) == (1, 1), n
@@ -153,7 +165,7 @@ def test_anything_that_can_see_a_set_keeps_it_from_being_reused():
 def test_another_stream_gets_another_set_and_output_pool_zero_always_allocates(golden):
     from qtttgym_amd import VecEnv
     E = golden["bits"].shape[0]
-    env = VecEnv(E)
+    env = VecEnv(E, output_pool=4)
     a, b = _inputs(golden, 0)
     o, r, tm, _, _ = env.step(a, b)
     p0 = r.data_ptr()
@@ -181,7 +193,7 @@ def test_default_step_with_a_device_step_counter_and_inside_a_graph():
     write into the graph's own pool (never into a pooled set) and replay bit-identically to eager steps."""
     from qtttgym_amd import VecEnv
     n, T = 4096, 6
-    ref, env = VecEnv(n, seed=9, auto_reset=True), VecEnv(n, seed=9, auto_reset=True)
+    ref, env = VecEnv(n, seed=9, auto_reset=True), VecEnv(n, seed=9, auto_reset=True, output_pool=2)
     acts = torch.empty((T, n, 2), dtype=torch.uint8, device="cuda")
     want = []
     for t in range(T):
