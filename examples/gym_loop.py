@@ -16,9 +16,8 @@ policy that depends on `obs["classical"]`.
 Aliasing: the loop consumes each observation at once, so it asks for the zero-copy form
 (`copy_obs=False`: the returned tensors are the environment's own buffers and the NEXT step overwrites
 them).  A caller that keeps observations — a replay buffer storing (obs, next_obs) — uses the default
-`env.step(action)`, which returns fresh tensors every call, still from ONE kernel: `--fresh` runs the loop that way
-(the names are rebound every step, so the environment alternates between two sets of output tensors and allocates
-nothing per step).
+`env.step(action)`, which returns fresh tensors every call (one allocation from torch's caching allocator, carved into the
+eight tensors), still from ONE kernel: `--fresh` runs the loop that way.
 """
 import argparse
 import os
