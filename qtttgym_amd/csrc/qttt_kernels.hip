@@ -186,28 +186,37 @@ extern "C" {
 
 // Env.reset INCLUDING the observation it returns (env.py:55-57,68-85): the empty board's observation is constant
 // (classical -1, no quantum states: 255 pad and length 0, turn 0), so state and observation are seven byte fills in
-// one launch: blockIdx.y = which buffer, 16-byte non-temporal stores, the unaligned head / tail of a caller's odd
-// pointer bytewise.
+// one launch.  The seven buffers' 16-byte pieces are numbered through (first[k] = pieces in front of buffer k): every
+// thread of the grid stores one piece, non-temporally; the unaligned head / tail of a caller's odd pointer is written
+// bytewise by the first workgroup.
 namespace {
 struct FillSegs {
     uint8_t *p[7];
     int64_t bytes[7];
+    int64_t first[8];                                        // prefix sums of the 16-byte piece counts
     u32 word[7];                                             // the fill byte, four times
 };
+__device__ __forceinline__ int64_t fill_head(const uint8_t *p, int64_t nb) {
+    const int64_t h = (int64_t)((16u - (u32)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u);
+    return h < nb ? h : nb;
+}
 __global__ __launch_bounds__(256) void reset_observe_kernel(FillSegs f) {
-    const u32 seg = blockIdx.y;
-    uint8_t *p = f.p[seg];
-    const int64_t nb = f.bytes[seg];
-    const u32 w = f.word[seg];
-    int64_t head = (int64_t)((16u - (u32)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u);
-    if (head > nb) head = nb;
-    const int64_t nvec = (nb - head) >> 4;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < nvec) __builtin_nontemporal_store(u32x4{w, w, w, w}, reinterpret_cast<u32x4 *>(p + head) + i);
-    if (blockIdx.x == 0 && threadIdx.x < 32) {
-        const int64_t k = threadIdx.x & 15;
-        if (threadIdx.x < 16) { if (k < head) p[k] = (uint8_t)w; }
-        else { const int64_t off = head + (nvec << 4) + k; if (off < nb) p[off] = (uint8_t)w; }
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < f.first[7]) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 7; ++j) k += g >= f.first[j] ? 1 : 0;
+        const u32 w = f.word[k];
+        uint8_t *p = f.p[k];
+        __builtin_nontemporal_store(u32x4{w, w, w, w}, reinterpret_cast<u32x4 *>(p + fill_head(p, f.bytes[k])) + (g - f.first[k]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 7 * 32) {           // 16 head + 16 tail bytes per buffer
+        const int k = threadIdx.x >> 5;
+        const int64_t j = threadIdx.x & 15;
+        uint8_t *p = f.p[k];
+        const int64_t nb = f.bytes[k], head = fill_head(p, nb), nvec = f.first[k + 1] - f.first[k];
+        if ((threadIdx.x & 31) < 16) { if (j < head) p[j] = (uint8_t)f.word[k]; }
+        else { const int64_t off = head + (nvec << 4) + j; if (off < nb) p[off] = (uint8_t)f.word[k]; }
     }
 }
 }  // namespace
@@ -222,10 +231,15 @@ int qttt_reset_observe(void *state, int8_t *classical, uint8_t *q_p1, uint8_t *q
     uint8_t *ptrs[7] = {static_cast<uint8_t *>(state), reinterpret_cast<uint8_t *>(classical), q_p1, q_p1_len, q_p2, q_p2_len, turn};
     const int64_t bytes[7] = {sb, 9 * n, 10 * n, n, 8 * n, n, n};
     const u32 words[7] = {0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u, 0u};
-    int64_t most = 0;
-    for (int k = 0; k < 7; ++k) { f.p[k] = ptrs[k]; f.bytes[k] = bytes[k]; f.word[k] = words[k]; if (bytes[k] > most) most = bytes[k]; }
-    const unsigned gx = (unsigned)(((most >> 4) + 255) / 256);
-    hipLaunchKernelGGL(reset_observe_kernel, dim3(gx ? gx : 1u, 7u), dim3(256), 0, (hipStream_t)stream, f);
+    f.first[0] = 0;
+    for (int k = 0; k < 7; ++k) {
+        f.p[k] = ptrs[k]; f.bytes[k] = bytes[k]; f.word[k] = words[k];
+        int64_t head = (int64_t)((16u - (u32)(reinterpret_cast<uintptr_t>(ptrs[k]) & 15u)) & 15u);
+        if (head > bytes[k]) head = bytes[k];
+        f.first[k + 1] = f.first[k] + ((bytes[k] - head) >> 4);
+    }
+    const unsigned gx = (unsigned)((f.first[7] + 255) / 256);
+    hipLaunchKernelGGL(reset_observe_kernel, dim3(gx ? gx : 1u), dim3(256), 0, (hipStream_t)stream, f);
     return launch_status();
 }
 

@@ -270,3 +270,37 @@ def test_zero_boards_and_one_board():
     assert o2["classical"][0].tolist() == [1, 0, -1, -1, -1, -1, -1, -1, -1] and int(o2["turn"]) == 0
     assert o["classical"][0].tolist() == [-1] * 9                                      # step 1's tensors are still step 1's
     assert r2.view(torch.int32).item() == -(2 ** 31) and not bool(tm2)                 # -0.0 (env.py:49)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 1000, 4097, 65537, 300001])
+def test_reset_observe_writes_exactly_its_buffers_at_any_alignment(n):
+    """include/qttt.h qttt_reset_observe (Env.reset with its observation, env.py:55-57,68-85): seven fills in one launch,
+    16-byte pieces + the unaligned head / tail of a caller's odd pointer bytewise.  Every output at every byte offset
+    0..3 and 13 into a guard-filled buffer: the values are the empty board's, the guard bytes around them untouched;
+    the state equals qttt_reset's."""
+    from qtttgym_amd import VecEnv, _native
+    L = _native.lib()
+    env, ref = VecEnv(n, seed=1), VecEnv(n, seed=1)
+    for _ in range(3):
+        env.step_raw(env.sample_actions())
+    ref.reset_raw()
+    sizes = {"classical": 9 * n, "q_p1": 10 * n, "q_p1_len": n, "q_p2": 8 * n, "q_p2_len": n, "turn": n}
+    want = {"classical": 255, "q_p1": 255, "q_p1_len": 0, "q_p2": 255, "q_p2_len": 0, "turn": 0}
+    GUARD, FILL = 64, 0x5A
+    for shift in (0, 1, 2, 3, 13):
+        bufs = {k: torch.full((GUARD + shift + b + GUARD,), FILL, dtype=torch.uint8, device="cuda") for k, b in sizes.items()}
+        ptr = {k: bufs[k].data_ptr() + GUARD + shift for k in sizes}
+        rc = L.qttt_reset_observe(env.state.data_ptr(), ptr["classical"], ptr["q_p1"], ptr["q_p1_len"], ptr["q_p2"],
+                                  ptr["q_p2_len"], ptr["turn"], n, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for k, b in sizes.items():
+            t = bufs[k]
+            lo = GUARD + shift
+            assert bool((t[:lo] == FILL).all()) and bool((t[lo + b:] == FILL).all()), (k, shift, "guard")
+            assert bool((t[lo:lo + b] == want[k]).all()), (k, shift)
+        assert torch.equal(env.state, ref.state)
+        for _ in range(2):                                   # dirty the state again for the next alignment
+            env.step_raw(env.sample_actions())
+    assert L.qttt_reset_observe(None, 1, 1, 1, 1, 1, 1, n, None) == -1 and L.qttt_reset_observe(env.state.data_ptr(), 1, 1, 1, 1, 1, 1, -1, None) == -2
+    assert L.qttt_reset_observe(None, None, None, None, None, None, None, 0, None) == 0
