@@ -102,7 +102,9 @@ def test_the_tail_of_the_default_line_carries_the_baseline_configs():
     g = legs["gym_default_1048576_boards"]
     assert c["gym_default_us"] == g["device_paced_us_per_step"] and c["gym_default_eager_us"] == g["us_per_step"]
     assert c["gym_us"] == legs["gym_1048576_boards"]["us_per_step"]
-    assert g["replay_matches_recording"] is True and g["mode"] == "gym-default" and "_fastviews.so" in g["outputs"]
+    assert g["replay_matches_recording"] is True and g["mode"] == "gym-default"
+    # (qtttgym_amd/_fastviews.so is optional: the line says which way the eight tensors were carved)
+    assert ("qtttgym_amd/_fastviews.so" in g["outputs"]) is os.path.exists(os.path.join(ROOT, "qtttgym_amd", "_fastviews.so"))
     assert 0 < g["us_per_step_with_output_pool_4"] < 14.5
     assert g["device_paced_us_per_step"] < 13.0 + 1.5, g       # asked: <= 13 us on a typical box (the pool's boxes differ by 7 %)
     assert abs(c["config1_us"] - d["ms_per_step"] * 1e3) < 1e-9 and abs(c["config1_frac"] - r["frac"]) < 1e-12
