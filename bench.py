@@ -266,23 +266,26 @@ def cpu_baseline(actions_host, seed, budget_s):
 def python_interpreter_line(actions_host, seed, budget_s=2.0):
     """The like-for-like interpreter-speed line: oracle/py_env.py, a pure-Python
     single-board restatement with the reference's own data structures returning what Env.step returns (the
-    observation dict too, env.py:46,68-85), one core, ~2 s."""
+    observation dict too, env.py:46,68-85), one core, ~2 s.  Actions and collapse bits are turned into Python ints
+    BEFORE the clock starts (the reference's caller holds Python ints too): what is timed is the step calls and the
+    auto-reset, the figure tools/facade_latency.py prints as interpreter_Env.step_us."""
     import oracle
     from oracle.py_env import PyEnv
-    T = actions_host.shape[0]
-    n_boards = actions_host.shape[1]
+    T = min(actions_host.shape[0], 64)
+    n_boards = min(actions_host.shape[1], 512)
+    plan = [[(int(actions_host[t, b, 0]), int(actions_host[t, b, 1]), int(oracle.collapse_bit(seed, b, t))) for t in range(T)]
+            for b in range(n_boards)]
     done, b = 0, 0
     t_end = time.perf_counter() + budget_s
     t0 = time.perf_counter()
     while time.perf_counter() < t_end:
         env = PyEnv()
-        for t in range(min(T, 64)):
-            a0, a1 = int(actions_host[t, b, 0]), int(actions_host[t, b, 1])
-            _, _, term, _, _ = env.step_full(a0, a1, oracle.collapse_bit(seed, b, t))     # observation included (env.py:46)
-            done += 1
-            if term:
+        step = env.step_full
+        for a0, a1, bit in plan[b]:
+            if step(a0, a1, bit)[2]:
                 env.reset()          # auto-reset, like the workload
-        b = (b + 1) % n_boards
+        done += T
+        b = b + 1 if b + 1 < n_boards else 0
     return done / (time.perf_counter() - t0)
 
 
