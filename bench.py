@@ -817,7 +817,7 @@ def run(args):
             ret, prep_error = None, None
             try:
                 from qtttgym_amd.dist import gather_returns
-                fail = os.environ.get("QTTT_BENCH_FAIL_GATHER")          # test hooks (tests/test_round4_gpu.py, test_round5_gpu.py)
+                fail = os.environ.get("QTTT_BENCH_FAIL_GATHER")          # test hooks (tests/test_bench_contract_gpu.py, tests/test_bench_line_gpu.py)
                 if fail == "1" or (fail is not None and fail.startswith("rank") and int(fail[4:]) == rank):
                     raise RuntimeError("QTTT_BENCH_FAIL_GATHER=%s: injected failure of the returns gather" % fail)
                 ret = env._reward.clone().to(data_dev)

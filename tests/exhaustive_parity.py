@@ -3,7 +3,7 @@
 the empty board in <= D plies (every legal action, both branches of every collapse; D = 4: 1 906 489 positions):
 observe, check_win, export, node_info (winner, terminal, legal mask, CPython key), encode, and the fused playout
 (result, plies) from each of them.  The positions are enumerated on the device with qttt_expand and rebuilt for the
-oracle from their exported attributes (tests/test_round4_gpu.py checks that enumeration against the oracle's own to
+oracle from their exported attributes (tests/test_rows_tiles_and_keys_gpu.py checks that enumeration against the oracle's own to
 depth 3 and every step transition from it).      python3 tests/exhaustive_parity.py [D=4]
 (Test infrastructure, kept under tests/: it checks against oracle/ like the suite does; not collected by pytest.)"""
 import os

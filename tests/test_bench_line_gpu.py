@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # The GPU boxes of this pool allow at most 6 processes on a card at once, and the pytest process itself is one of them
 # once an earlier test has touched the GPU: the driver-shaped N = 8 command is rehearsed with 4 ranks here (4 + pytest
-# = 5); its eight-rank bookkeeping runs on CPU gloo ranks in tests/test_round5_cpu.py.
+# = 5); its eight-rank bookkeeping runs on CPU gloo ranks in tests/test_dist_bookkeeping_cpu.py.
 RANKS_ON_ONE_CARD = 4
 
 

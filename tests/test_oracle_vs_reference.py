@@ -151,7 +151,7 @@ def test_oracle_expand_equals_the_reference_step_exhaustively_to_depth_three():
     """Exhaustive link of the pin chain on the reference's side: from the empty board, every action at every position to
     depth 2 is run through the reference's own MCTS._step (unmodified mcts.py) — (1 + 36 + 1 332) x 36 = 49 284 calls —
     and through the oracle's qo_expand; the children (both collapse branches), their winner / terminal / legal
-    actions and Python hash are the same, position by position.  (tests/test_round4_gpu.py then holds the HIP side
+    actions and Python hash are the same, position by position.  (tests/test_rows_tiles_and_keys_gpu.py then holds the HIP side
     against the oracle over every position to depth 4.)"""
     import sys
     from ref_shim import REFERENCE_ROOT
