@@ -266,3 +266,14 @@ def test_bench_refuses_to_run_without_a_gpu():
     from qtttgym_amd import VecEnv, _native
     with pytest.raises(_native.QtttNativeError):
         VecEnv(4, device="cpu")
+
+
+def test_integration_md_names_every_exported_symbol():
+    """INTEGRATION.md §2's table is the map from the C ABI to the reference's interfaces: every function include/qttt.h
+    declares has its row."""
+    header = open(os.path.join(ROOT, "include", "qttt.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = sorted(set(re.findall(r"\b(qttt_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) == 30, declared
+    missing = [s for s in declared if "`%s" % s not in doc and s not in doc]
+    assert not missing, missing
