@@ -398,7 +398,9 @@ class VecEnv:
         copy_obs=True (default): the returned observation, reward and terminated are tensors nobody else holds — as
         the reference's Env.step builds new lists every call (env.py:46,68-85), a gym caller may keep (obs, next_obs)
         pairs, or every observation of an episode: one fresh allocation per call, carved into the eight tensors
-        (_fresh_outputs; VecEnv(output_pool=N) re-uses sets the caller has dropped instead).  copy_obs=False returns the environment's own buffers, overwritten by the next such step() /
+        (_fresh_outputs; VecEnv(output_pool=N) re-uses sets the caller has dropped instead).  The eight tensors of one
+        call share that one allocation (34 bytes per board + padding): keeping — or torch.save-ing — any one of them
+        keeps all of it, so a replay buffer that stores one field for long should store `.clone()`s.  copy_obs=False returns the environment's own buffers, overwritten by the next such step() /
         observ() — = step_observe_raw."""
         dev = self.state.device
         if not (torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == dev
