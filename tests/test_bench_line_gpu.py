@@ -108,6 +108,3 @@ def test_the_tail_of_the_default_line_carries_the_baseline_configs():
     assert 0 < g["us_per_step_with_output_pool_4"] < 14.5
     assert g["device_paced_us_per_step"] < 13.0 + 1.5, g       # asked: <= 13 us on a typical box (the pool's boxes differ by 7 %)
     assert abs(c["config1_us"] - d["ms_per_step"] * 1e3) < 1e-9 and abs(c["config1_frac"] - r["frac"]) < 1e-12
-    # a floor under the headline, far enough below what every box of the pool has shown (0.715 - 0.77 of the 8 TB/s spec at
-    # 1 M boards, 0.77 - 0.82 beyond the Infinity Cache) to catch a regression without tripping over a slow box
-    assert r["frac"] > 0.62 and c["beyond_cache_frac"] > 0.68 and d["value"] > 1.0e11, (r["frac"], c["beyond_cache_frac"])
